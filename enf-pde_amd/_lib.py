@@ -1,0 +1,85 @@
+"""ctypes binding of the C-ABI in include/enf_hip.h (libenf_hip.so, built in-tree by
+``make -C enf-pde_amd/csrc`` / ``__graft_entry__.build()``).  Fails loudly when the library is
+missing: there is no fallback path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libenf_hip.so")
+
+ENF_NUM_TENSORS = 46
+PREC = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic": 2, "ponita": 3,
+                 "abs_pos": 4, "rel_pos": 5, "norm_rel_pos": 6}
+
+EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
+           "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
+           "enf_backward_latents"]
+
+
+class EnfDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("B", "N", "Z", "H", "D", "C", "O", "dx", "invariant_id", "use_window", "precision")] + \
+               [("reserved", ctypes.c_int32 * 5)]
+
+
+class EnfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libenf_hip.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EnfError(f"{LIB_PATH} not found: build it with `make -C enf-pde_amd/csrc` "
+                       "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, sz, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t, ctypes.c_int
+    dp = ctypes.POINTER(EnfDesc)
+    lib.enf_abi_version.restype = ci
+    lib.enf_strerror.restype = ctypes.c_char_p
+    lib.enf_strerror.argtypes = [ci]
+    lib.enf_invariant_dim.argtypes = [ci, ci]
+    lib.enf_invariant_pose_dim.argtypes = [ci, ci]
+    lib.enf_check_desc.argtypes = [dp]
+    lib.enf_packed_weight_bytes.restype = sz
+    lib.enf_packed_weight_bytes.argtypes = [dp]
+    lib.enf_workspace_bytes.restype = sz
+    lib.enf_workspace_bytes.argtypes = [dp]
+    lib.enf_pack_weights.argtypes = [dp, ctypes.POINTER(vp), vp, vp]
+    lib.enf_forward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.enf_backward_latents.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    for name in ("enf_debug_gemm", "enf_debug_pack"):
+        getattr(lib, name).restype = ci
+    lib.enf_debug_gemm.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+    lib.enf_debug_pack.argtypes = [vp, vp, ci, ci, ci, vp]
+    if lib.enf_abi_version() != 1:
+        raise EnfError("libenf_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a negative return code to the exception the reference would raise."""
+    if rc == 0:
+        return
+    msg = load().enf_strerror(rc).decode()
+    if rc == -2:   # ENF_EINVARIANT: reference raises ValueError (invariant/__init__.py:44,78)
+        raise ValueError(msg)
+    if rc == -6:   # ENF_EDIM: reference asserts (invariant/__init__.py:28,31,62,65)
+        raise AssertionError(msg)
+    if rc == -3:
+        raise NotImplementedError(msg)
+    raise EnfError(f"libenf_hip error {rc}: {msg}")
+
+
+def make_desc(B, N, Z, H, D, C, O, dx, invariant_id, use_window, precision):
+    d = EnfDesc()
+    d.B, d.N, d.Z, d.H, d.D, d.C, d.O, d.dx = int(B), int(N), int(Z), int(H), int(D), int(C), int(O), int(dx)
+    d.invariant_id, d.use_window, d.precision = int(invariant_id), int(bool(use_window)), int(precision)
+    return d

@@ -1,0 +1,114 @@
+// enf_api.hip -- the C-ABI of include/enf_hip.h: validation, workspace carving, kernel sequencing.
+// No allocation, no host synchronisation, no global state besides one-time kernel attributes.
+#include <hip/hip_runtime.h>
+#include "enf_layout.h"
+
+extern "C" {
+int enf_launch_prologue(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, const float*, float*,
+                        float*, float*, hipStream_t);
+int enf_launch_prologue_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, const float*,
+                            const float*, const float*, float*, float*, float*, hipStream_t);
+int enf_launch_pair_fwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, float*, float*,
+                        hipStream_t);
+int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, const float*,
+                        const float*, const float*, float*, hipStream_t);
+int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
+                    int, hipStream_t);
+}
+
+extern "C" int enf_abi_version(void) { return ENF_ABI_VERSION; }
+
+extern "C" const char* enf_strerror(int code) {
+  switch (code) {
+    case ENF_OK: return "ok";
+    case ENF_EINVAL: return "invalid argument (null pointer or non-positive size)";
+    case ENF_EINVARIANT: return "Unknown invariant type";
+    case ENF_EUNSUPPORTED: return "shape not in the compiled kernel set (num_hidden in {64,128}, num_heads in {1,2}, num_out <= 32)";
+    case ENF_EWORKSPACE: return "workspace too small";
+    case ENF_ELAUNCH: return "HIP launch failed";
+    case ENF_EDIM: return "coordinate / pose width inconsistent with the invariant";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int enf_invariant_dim(int inv, int dx) {
+  const int i = enf_inv_dim(inv, dx);
+  return i < 0 ? ENF_EINVARIANT : i;
+}
+extern "C" int enf_invariant_pose_dim(int inv, int dx) {
+  const int i = enf_inv_pose_dim(inv, dx);
+  return i < 0 ? ENF_EINVARIANT : i;
+}
+
+extern "C" int enf_check_desc(const EnfDesc* d) {
+  if (!d) return ENF_EINVAL;
+  if (d->B <= 0 || d->N <= 0 || d->Z <= 0 || d->C <= 0 || d->O <= 0 || d->H <= 0 || d->D <= 0) return ENF_EINVAL;
+  if (d->invariant_id < 0 || d->invariant_id >= ENF_INV_COUNT) return ENF_EINVARIANT;
+  if (d->dx < 1 || d->dx > 3) return ENF_EDIM;
+  const bool two_d = d->invariant_id == ENF_INV_REL_POS_PERIODIC || d->invariant_id == ENF_INV_PONITA ||
+                     d->invariant_id == ENF_INV_LATITUDE_PERIODIC || d->invariant_id == ENF_INV_POLAR_PERIODIC;
+  if (two_d && d->dx != 2) return ENF_EDIM;     // reference: assert cfg.num_in == 2 (invariant/__init__.py:62,65)
+  if (!(d->D == 64 || d->D == 128)) return ENF_EUNSUPPORTED;
+  if (!(d->H == 1 || d->H == 2)) return ENF_EUNSUPPORTED;
+  if (d->O > 32) return ENF_EUNSUPPORTED;
+  if (d->precision != ENF_PREC_F32 && d->precision != ENF_PREC_BF16) return ENF_EINVAL;
+  return ENF_OK;
+}
+
+extern "C" size_t enf_packed_weight_bytes(const EnfDesc* d) {
+  if (enf_check_desc(d) != ENF_OK) return 0;
+  return enf_layout(enf_dims(d)).total;
+}
+
+extern "C" size_t enf_workspace_bytes(const EnfDesc* d) {
+  if (enf_check_desc(d) != ENF_OK) return 0;
+  return enf_workspace(enf_dims(d)).total;
+}
+
+extern "C" int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
+                           const float* sigma, const void* packed, float* out, float* ybar, float* lse, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (!x || !p || !a || !packed || !out || !workspace) return ENF_EINVAL;
+  if (d->use_window && !sigma) return ENF_EINVAL;
+  const EnfDims m = enf_dims(d);
+  const EnfLayout L = enf_layout(m);
+  const EnfWorkspace W = enf_workspace(m);
+  if (workspace_bytes < W.total) return ENF_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+  const char* blob = (const char*)packed;
+  float* yb = ybar ? ybar : F(W.ybar);
+  float* ls = lse ? lse : F(W.lse);
+  if ((rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
+  if ((rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, st))) return rc;
+  if ((rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, nullptr, 0, st))) return rc;
+  return ENF_OK;
+}
+
+extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
+                                    const float* sigma, const void* packed, const float* ybar, const float* lse,
+                                    const float* dout, float* dp, float* da, float* dsigma, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (!x || !p || !a || !packed || !ybar || !lse || !dout || !dp || !da || !dsigma || !workspace) return ENF_EINVAL;
+  if (d->use_window && !sigma) return ENF_EINVAL;
+  const EnfDims m = enf_dims(d);
+  const EnfLayout L = enf_layout(m);
+  const EnfWorkspace W = enf_workspace(m);
+  if (workspace_bytes < W.total) return ENF_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+  const char* blob = (const char*)packed;
+  // the latent table is recomputed (cheap) so the call does not depend on workspace contents
+  if ((rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
+  if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, st))) return rc;
+  if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
+  if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), st))) return rc;
+  if ((rc = enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st))) return rc;
+  return ENF_OK;
+}

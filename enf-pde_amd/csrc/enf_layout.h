@@ -1,0 +1,172 @@
+// enf_layout.h -- byte layout of the packed weight blob and of the workspace (host + device).
+//
+// The blob holds, for one EquivariantCrossAttentionNeF weight tree:
+//   * fp32 row-major matrices/vectors used by the latent prologue (per-latent work, VALU),
+//   * fp32 bias / constant vectors used as accumulator initialisers in the per-pair chain,
+//   * the per-pair and per-query weight panels in MFMA A-operand fragment order
+//     ("panel": out-blocks x in-blocks x fragment), bf16 or fp32 depending on EnfDesc.precision,
+//   * the same panels transposed for the backward chain (dX = W dY),
+//   * plain fp32 copies of every folded matrix (inputs of the panel packer).
+// Folds (exact algebra, fp32; DESIGN.md "Folds"):
+//   AF  = rffv.linear_final @ inv_emb_to_v.Dense_0                    (RFF:46 + ECA:17)
+//   AGB = diag(LayerNorm_0.scale) @ inv_emb_to_v.Dense_1, per head 32-wide blocks [g b g b ..] (ECA:19-20,115)
+//   MU_h = scale * rffq.linear_final @ inv_emb_to_q[:, hD:(h+1)D]      (RFF:46 + ECA:92,134)
+//   WB  = blockdiag_h(diag(mixer.LN.scale) @ mixer.Dense_1) @ out_proj @ ffn.Dense_0   (ECA:20,144-150; NEF:66)
+//   WF1 = diag(ffn.LN.scale) @ ffn.Dense_1                             (ECA:19-20)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/enf_hip.h"
+
+#ifdef __HIPCC__
+#define ENF_HD __host__ __device__
+#else
+#define ENF_HD
+#endif
+
+struct EnfDims {
+  int B, N, Z, H, D, C, O, dx, dp, I, inv, use_window, bf16;
+  int HD;      // H*D
+  int KB;      // D/32   in/out blocks of a D-wide activation
+  int KBH;     // HD/32
+  int OB;      // ceil(O/32) output blocks of the last layer
+};
+
+ENF_HD inline int enf_inv_dim(int inv, int dx) {
+  switch (inv) {
+    case ENF_INV_REL_POS_PERIODIC: return 4;
+    case ENF_INV_LATITUDE_PERIODIC: return 4;
+    case ENF_INV_POLAR_PERIODIC: return 1;
+    case ENF_INV_PONITA: return 2;
+    case ENF_INV_ABS_POS: return dx;
+    case ENF_INV_REL_POS: return dx;
+    case ENF_INV_NORM_REL_POS: return 1;
+    default: return -1;
+  }
+}
+ENF_HD inline int enf_inv_pose_dim(int inv, int dx) {
+  switch (inv) {
+    case ENF_INV_REL_POS_PERIODIC: return 2;
+    case ENF_INV_LATITUDE_PERIODIC: return 2;
+    case ENF_INV_POLAR_PERIODIC: return 2;
+    case ENF_INV_PONITA: return 3;            // (pos_x, pos_y, theta)
+    case ENF_INV_ABS_POS: return dx;
+    case ENF_INV_REL_POS: return dx;
+    case ENF_INV_NORM_REL_POS: return dx;
+    default: return -1;
+  }
+}
+
+inline EnfDims enf_dims(const EnfDesc* d) {
+  EnfDims m;
+  m.B = d->B; m.N = d->N; m.Z = d->Z; m.H = d->H; m.D = d->D; m.C = d->C; m.O = d->O;
+  m.dx = d->dx; m.inv = d->invariant_id; m.use_window = d->use_window;
+  m.bf16 = d->precision == ENF_PREC_BF16;
+  m.I = enf_inv_dim(m.inv, m.dx); m.dp = enf_inv_pose_dim(m.inv, m.dx);
+  m.HD = m.H * m.D; m.KB = m.D / 32; m.KBH = m.HD / 32; m.OB = (m.O + 31) / 32;
+  return m;
+}
+
+// bytes of one (out-block, in-block) fragment group: 32x32 weights
+ENF_HD inline size_t enf_frag_bytes(int bf16) { return bf16 ? 2048 : 4096; }
+ENF_HD inline size_t enf_panel_bytes(int out_blocks, int in_blocks, int bf16) {
+  return (size_t)out_blocks * in_blocks * enf_frag_bytes(bf16);
+}
+
+struct EnfLayout {
+  // ---- prologue, fp32 row-major (in,out)
+  size_t stem_w, stem_b, lna_g, lna_b, wk, bk, wv, bv;
+  size_t mu;     // H x (D x D): u_h[i] = sum_d mu[h][i][d] * k_h[d]
+  size_t cvec;   // H x D:       c_h    = sum_d cvec[h][d] * k_h[d]
+  // ---- coefficient A-operands of t = coeff^T inv (fp32 32x32x2 MFMA), [D/64 blocks][2 k-pairs][64 lanes]
+  size_t acq, acv;
+  // ---- accumulator-init vectors, fp32
+  size_t bq1, bv1, bf, bgb, bm;         // D, D, D, 2HD (panel order), D
+  size_t bB, bF1, bO0, bO2, bO4;        // HD, HD, D, D, 32*OB
+  // ---- forward panels (A operand = W^T, out x in)
+  size_t aq1, av1, af, agb, am;         // KBxKB each; agb: 2H stages of KBxKB
+  size_t atb, atf1, ato0, ato2, ato4;   // KBHxKBH, KBHxKBH, KBxKBH, KBxKB, OBxKB
+  // ---- backward panels (A operand = W, in x out): dX = W dY
+  size_t gq1, gv1, gf, ggb, gm;         // KBxKB; ggb: KB x (2H*KB)  (out = D, in = 2HD)
+  size_t gtb, gtf1, gto0, gto2, gto4;   // KBHxKBH, KBHxKBH, KBHxKB, KBxKB, KBxOB
+  // ---- plain fp32 (in,out) copies of folded matrices
+  size_t p_af, p_agb, p_wb, p_wf1, p_tmp, p_o4;   // DxD, Dx2HD, HDxHD, HDxHD, HDxHD, Dx(32*OB)
+  size_t p_mxw;                         // DxD: diag(mixer LN scale) @ mixer Dense_1
+  size_t p_mxb;                         // D: mixer LN bias @ Dense_1 + Dense_1 bias
+  size_t total;
+};
+
+inline size_t enf_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline EnfLayout enf_layout(const EnfDims& m) {
+  EnfLayout L;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = enf_align(o + bytes); return r; };
+  const size_t f = sizeof(float);
+  const int D = m.D, HD = m.HD, H = m.H, C = m.C;
+  L.stem_w = take(f * C * D); L.stem_b = take(f * D); L.lna_g = take(f * D); L.lna_b = take(f * D);
+  L.wk = take(f * D * HD); L.bk = take(f * HD); L.wv = take(f * D * HD); L.bv = take(f * HD);
+  L.mu = take(f * H * D * D); L.cvec = take(f * H * D);
+  L.acq = take(f * (D / 64) * 2 * 64); L.acv = take(f * (D / 64) * 2 * 64);
+  L.bq1 = take(f * D); L.bv1 = take(f * D); L.bf = take(f * D); L.bgb = take(f * 2 * HD); L.bm = take(f * D);
+  L.bB = take(f * HD); L.bF1 = take(f * HD); L.bO0 = take(f * D); L.bO2 = take(f * D); L.bO4 = take(f * 32 * m.OB);
+  const int KB = m.KB, KBH = m.KBH, OB = m.OB, bf = m.bf16;
+  L.aq1 = take(enf_panel_bytes(KB, KB, bf)); L.av1 = take(enf_panel_bytes(KB, KB, bf));
+  L.af = take(enf_panel_bytes(KB, KB, bf)); L.agb = take(enf_panel_bytes(2 * H * KB, KB, bf));
+  L.am = take(enf_panel_bytes(KB, KB, bf));
+  L.atb = take(enf_panel_bytes(KBH, KBH, bf)); L.atf1 = take(enf_panel_bytes(KBH, KBH, bf));
+  L.ato0 = take(enf_panel_bytes(KB, KBH, bf)); L.ato2 = take(enf_panel_bytes(KB, KB, bf));
+  L.ato4 = take(enf_panel_bytes(OB, KB, bf));
+  L.gq1 = take(enf_panel_bytes(KB, KB, bf)); L.gv1 = take(enf_panel_bytes(KB, KB, bf));
+  L.gf = take(enf_panel_bytes(KB, KB, bf)); L.ggb = take(enf_panel_bytes(KB, 2 * H * KB, bf));
+  L.gm = take(enf_panel_bytes(KB, KB, bf));
+  L.gtb = take(enf_panel_bytes(KBH, KBH, bf)); L.gtf1 = take(enf_panel_bytes(KBH, KBH, bf));
+  L.gto0 = take(enf_panel_bytes(KBH, KB, bf)); L.gto2 = take(enf_panel_bytes(KB, KB, bf));
+  L.gto4 = take(enf_panel_bytes(KB, OB, bf));
+  L.p_af = take(f * D * D); L.p_agb = take(f * D * 2 * HD); L.p_wb = take(f * HD * HD);
+  L.p_wf1 = take(f * HD * HD); L.p_tmp = take(f * HD * HD); L.p_o4 = take(f * D * 32 * OB);
+  L.p_mxw = take(f * D * D); L.p_mxb = take(f * D);
+  L.total = o;
+  return L;
+}
+
+// ---- latent table: one row per (b, z), written by the prologue, read by the pair kernels
+// [ u (H*D) | v0 (H*D) | pose (4) | wcoef (1) | pad (3) | c (H) | pad ] fp32, 16-byte aligned fields
+ENF_HD inline int enf_lt_stride(int H, int D) { return ((2 * H * D + 8 + H) + 63) & ~63; }
+ENF_HD inline int enf_lt_off_u(int, int) { return 0; }
+ENF_HD inline int enf_lt_off_v0(int H, int D) { return H * D; }
+ENF_HD inline int enf_lt_off_pose(int H, int D) { return 2 * H * D; }
+ENF_HD inline int enf_lt_off_wcoef(int H, int D) { return 2 * H * D + 4; }
+ENF_HD inline int enf_lt_off_c(int H, int D) { return 2 * H * D + 8; }
+
+struct EnfWorkspace {
+  size_t lt;        // B*Z*lt_stride floats: latent table
+  size_t an;        // B*Z*(D + D + 2) floats: stem output, a_norm, LN mean/rstd (prologue backward)
+  size_t kv;        // B*Z*2*HD floats: k | v0-as-computed (prologue backward)
+  size_t ybar;      // B*N*HD floats (used when the caller passes ybar == NULL)
+  size_t lse;       // B*N*H
+  size_t dybar;     // B*N*HD  gradient of ybar (backward)
+  size_t delta;     // B*N*H   sum_d dybar*ybar (backward)
+  size_t tail_act;  // B*N*(2*HD + 2*D + 2) tail pre-activations + LN stats (backward recompute cache)
+  size_t dlt;       // B*Z*lt_stride floats: gradient of the latent table (backward)
+  size_t total;
+};
+
+inline EnfWorkspace enf_workspace(const EnfDims& m) {
+  EnfWorkspace W;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = enf_align(o + bytes); return r; };
+  const size_t f = sizeof(float);
+  const size_t BZ = (size_t)m.B * m.Z, BN = (size_t)m.B * m.N;
+  W.lt = take(f * BZ * enf_lt_stride(m.H, m.D));
+  W.an = take(f * BZ * (2 * m.D + 2));
+  W.kv = take(f * BZ * 2 * m.HD);
+  W.ybar = take(f * BN * m.HD);
+  W.lse = take(f * BN * m.H);
+  W.dybar = take(f * BN * m.HD);
+  W.delta = take(f * BN * m.H);
+  W.tail_act = take(f * BN * (2 * m.HD + 2 * m.D + 2));
+  W.dlt = take(f * BZ * enf_lt_stride(m.H, m.D));
+  W.total = o;
+  return W;
+}

@@ -1,0 +1,459 @@
+// enf_pack.hip -- K0 (weight packing + exact folds) and K1 (latent prologue, forward + backward).
+//
+// K0 turns the Flax weight tree of EquivariantCrossAttentionNeF into the packed
+// blob described in enf_layout.h.  K1 is the per-latent part of the decoder:
+//   latent_stem (NEF:220) -> layer_norm_attn (NEF:56) -> a_to_k / a_to_v (ECA:93-94)
+// followed by the fold of inv_emb_to_q into the keys (ECA:92 + ECA:134):
+//   att[n,z,h] = scale * q[n,z,h,:] . k[z,h,:]
+//              = h1[n,z,:] . u[z,h,:] + c[z,h],   u = scale * W2 Wq_h k_h,  c = scale * (b2 Wq_h + bq_h) . k_h
+// where h1 is the relu layer of the query RFFNet and (W2, b2) its linear_final (RFF:46).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "enf_layout.h"
+
+#define CK(x) do { if ((x) != hipSuccess) return ENF_ELAUNCH; } while (0)
+
+// ---------------------------------------------------------------- small dense helpers (fp32)
+// C[i][j] = (acc ? C[i][j] : 0) + alpha * (sum_k A[i*lda+k] * B[k*ldb+j] + (addv ? addv[j] : 0))
+__global__ void mm_kernel(float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
+                          float alpha, const float* addv, int acc) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= N || i >= M) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf(A[(size_t)i * lda + k], B[(size_t)k * ldb + j], s);
+  if (addv) s += addv[j];
+  s *= alpha;
+  C[(size_t)i * ldc + j] = acc ? C[(size_t)i * ldc + j] + s : s;
+}
+// dst[i][j] = g[i] * src[i][j]
+__global__ void rowscale_kernel(float* dst, const float* src, const float* g, int rows, int cols) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j < cols && i < rows) dst[(size_t)i * cols + j] = g[i] * src[(size_t)i * cols + j];
+}
+// gamma/beta column reorder (ECA:115 split: gamma = first HD columns, beta = last HD): per head h the
+// 32-wide blocks alternate [g_h blk0 | b_h blk0 | g_h blk1 | b_h blk1 ..] so that one staged slice of the
+// panel holds gamma AND beta of the same features:
+//   dst col h*2D + (2m+t)*32 + i  <-  src col t*HD + h*D + 32m + i      (t: 0 gamma, 1 beta); rows scaled by g
+__global__ void reorder_gb_kernel(float* dst, const float* src, const float* g, int rows, int H, int D) {
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  const int HD = H * D;
+  if (jj >= 2 * HD || i >= rows) return;
+  const int h = jj / (2 * D), w = jj % (2 * D), blk = w / 32, ii = w % 32, m = blk >> 1, t = blk & 1;
+  dst[(size_t)i * 2 * HD + jj] = (g ? g[i] : 1.f) * src[(size_t)i * 2 * HD + t * HD + h * D + 32 * m + ii];
+}
+// zero-padded copy of a (rows x cols) matrix into (rows x cols_pad)
+__global__ void padcopy_kernel(float* dst, const float* src, int rows, int cols, int cols_pad) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j < cols_pad && i < rows) dst[(size_t)i * cols_pad + j] = j < cols ? src[(size_t)i * cols + j] : 0.f;
+}
+// RFF coefficient A-operand of t = coeff^T inv (v_mfma_f32_32x32x2_f32): [m][kk][lane]
+__global__ void coef_frag_kernel(float* dst, const float* coeff, int I, int Dh /*D/2*/) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = (Dh / 32) * 2 * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63, kk = (idx >> 6) & 1, m = idx >> 7;
+  const int c = 2 * kk + (lane >> 5), t = 32 * m + (lane & 31);
+  dst[idx] = c < I ? coeff[(size_t)c * Dh + t] : 0.f;
+}
+
+// ---------------------------------------------------------------- MFMA A-operand panel packer
+// A[r][k] (R x K, both multiples of 32) = trans ? W[r*ldw + k] : W[k*ldw + r].
+// bf16: byte (((m*KBin+blk)*2+s)*64+lane)*16 + 2j  <- A[32m + (lane&31)][32blk + 16s + 8(j>>2) + 4(lane>>5) + (j&3)]
+// fp32: byte (((m*KBin+blk)*4+r4)*64+lane)*16 + 4i <- A[32m + (lane&31)][32blk + 8 r4 + 4(lane>>5) + i]
+// (the k order is the one in which a 32x32 accumulator presents its rows as the next B operand)
+__global__ void pack_panel_kernel(void* dst, const float* W, int ldw, int R, int K, int trans, int bf16,
+                                  int Rvalid, int Kvalid) {
+  const int KBin = K / 32;
+  const size_t total = (size_t)R * K;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int r, k;
+  if (bf16) {
+    const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1;
+    const size_t g = e >> 10;  // m*KBin + blk
+    const int blk = g % KBin, m = g / KBin;
+    r = 32 * m + (lane & 31);
+    k = 32 * blk + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+  } else {
+    const int i = e & 3, lane = (e >> 2) & 63, r4 = (e >> 8) & 3;
+    const size_t g = e >> 10;
+    const int blk = g % KBin, m = g / KBin;
+    r = 32 * m + (lane & 31);
+    k = 32 * blk + 8 * r4 + 4 * (lane >> 5) + i;
+  }
+  float v = 0.f;
+  if (r < Rvalid && k < Kvalid) v = trans ? W[(size_t)r * ldw + k] : W[(size_t)k * ldw + r];
+  if (bf16) reinterpret_cast<__bf16*>(dst)[e] = (__bf16)v;
+  else reinterpret_cast<float*>(dst)[e] = v;
+}
+
+static inline int mm(hipStream_t st, float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N,
+                     int K, float alpha, const float* addv, int acc) {
+  dim3 g((N + 127) / 128, M);
+  hipLaunchKernelGGL(mm_kernel, g, dim3(128), 0, st, C, ldc, A, lda, B, ldb, M, N, K, alpha, addv, acc);
+  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+}
+static inline int pack_panel(hipStream_t st, char* blob, size_t off, const float* W, int ldw, int R, int K, int trans,
+                             int bf16, int Rvalid = -1, int Kvalid = -1) {
+  const size_t total = (size_t)R * K;
+  hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (void*)(blob + off), W,
+                     ldw, R, K, trans, bf16, Rvalid < 0 ? R : Rvalid, Kvalid < 0 ? K : Kvalid);
+  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+}
+
+// test-only: pack a plain fp32 (K x M row-major, W[k][m]) matrix as the A operand A[m][k] = W[k][m]
+extern "C" int enf_debug_pack(void* dst, const float* W, int M, int K, int bf16, void* stream) {
+  const size_t total = (size_t)M * K;
+  hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, W, M,
+                     M, K, 0, bf16, M, K);
+  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+}
+
+extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* packed, void* stream) {
+  if (!d || !T || !packed) return ENF_EINVAL;
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  for (int i = 0; i < ENF_NUM_TENSORS; ++i)
+    if (!T[i]) return ENF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const EnfDims m = enf_dims(d);
+  const EnfLayout L = enf_layout(m);
+  char* blob = (char*)packed;
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
+  const int D = m.D, H = m.H, HD = m.HD, C = m.C, O = m.O, I = m.I, OP = 32 * m.OB;
+  const size_t f = sizeof(float);
+  const float scale = 1.0f / sqrtf((float)D);  // ECA:59
+  auto cp = [&](size_t off, const float* src, size_t n) {
+    return hipMemcpyAsync(blob + off, src, n * f, hipMemcpyDeviceToDevice, st);
+  };
+  // ---- prologue tensors
+  CK(cp(L.stem_w, T[ENF_W_STEM_W], (size_t)C * D)); CK(cp(L.stem_b, T[ENF_W_STEM_B], D));
+  CK(cp(L.lna_g, T[ENF_W_LNA_G], D)); CK(cp(L.lna_b, T[ENF_W_LNA_B], D));
+  CK(cp(L.wk, T[ENF_W_K_W], (size_t)D * HD)); CK(cp(L.bk, T[ENF_W_K_B], HD));
+  CK(cp(L.wv, T[ENF_W_V_W], (size_t)D * HD)); CK(cp(L.bv, T[ENF_W_V_B], HD));
+  for (int h = 0; h < H; ++h) {
+    if ((rc = mm(st, F(L.mu) + (size_t)h * D * D, D, T[ENF_W_RQ_W2], D, T[ENF_W_Q_W] + h * D, HD, D, D, D, scale, nullptr, 0))) return rc;
+    if ((rc = mm(st, F(L.cvec) + (size_t)h * D, D, T[ENF_W_RQ_B2], D, T[ENF_W_Q_W] + h * D, HD, 1, D, D, scale, T[ENF_W_Q_B] + h * D, 0))) return rc;
+  }
+  // ---- RFF coefficient fragments
+  {
+    const int tot = (D / 64) * 2 * 64;
+    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, F(L.acq), T[ENF_W_RQ_COEF], I, D / 2);
+    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, F(L.acv), T[ENF_W_RV_COEF], I, D / 2);
+  }
+  // ---- per-pair biases
+  CK(cp(L.bq1, T[ENF_W_RQ_B1], D)); CK(cp(L.bv1, T[ENF_W_RV_B1], D)); CK(cp(L.bm, T[ENF_W_MX_B0], D));
+  if ((rc = mm(st, F(L.bf), D, T[ENF_W_RV_B2], D, T[ENF_W_F1_W0], D, 1, D, D, 1.f, T[ENF_W_F1_B0], 0))) return rc;
+  // bgb = LN.bias @ Dense_1 + Dense_1.bias, reordered like the panel (see reorder_gb_kernel)
+  if ((rc = mm(st, F(L.p_tmp), 2 * HD, T[ENF_W_F1_BE], D, T[ENF_W_F1_W1], 2 * HD, 1, 2 * HD, D, 1.f, T[ENF_W_F1_B1], 0))) return rc;
+  hipLaunchKernelGGL(reorder_gb_kernel, dim3((2 * HD + 127) / 128, 1), dim3(128), 0, st, F(L.bgb), F(L.p_tmp), (const float*)nullptr, 1, H, D);
+  // ---- folded plain matrices
+  if ((rc = mm(st, F(L.p_af), D, T[ENF_W_RV_W2], D, T[ENF_W_F1_W0], D, D, D, D, 1.f, nullptr, 0))) return rc;
+  hipLaunchKernelGGL(reorder_gb_kernel, dim3((2 * HD + 127) / 128, D), dim3(128), 0, st, F(L.p_agb), T[ENF_W_F1_W1], T[ENF_W_F1_G], D, H, D);
+  hipLaunchKernelGGL(rowscale_kernel, dim3((D + 127) / 128, D), dim3(128), 0, st, F(L.p_mxw), T[ENF_W_MX_W1], T[ENF_W_MX_G], D, D);
+  if ((rc = mm(st, F(L.p_mxb), D, T[ENF_W_MX_BE], D, T[ENF_W_MX_W1], D, 1, D, D, 1.f, T[ENF_W_MX_B1], 0))) return rc;
+  if ((rc = mm(st, F(L.p_tmp), HD, T[ENF_W_AO_W], HD, T[ENF_W_FF_W0], HD, HD, HD, HD, 1.f, nullptr, 0))) return rc;
+  if ((rc = mm(st, F(L.bB), HD, T[ENF_W_AO_B], HD, T[ENF_W_FF_W0], HD, 1, HD, HD, 1.f, T[ENF_W_FF_B0], 0))) return rc;
+  for (int h = 0; h < H; ++h) {
+    if ((rc = mm(st, F(L.p_wb) + (size_t)h * D * HD, HD, F(L.p_mxw), D, F(L.p_tmp) + (size_t)h * D * HD, HD, D, HD, D, 1.f, nullptr, 0))) return rc;
+    if ((rc = mm(st, F(L.bB), HD, F(L.p_mxb), D, F(L.p_tmp) + (size_t)h * D * HD, HD, 1, HD, D, 1.f, nullptr, 1))) return rc;
+  }
+  hipLaunchKernelGGL(rowscale_kernel, dim3((HD + 127) / 128, HD), dim3(128), 0, st, F(L.p_wf1), T[ENF_W_FF_W1], T[ENF_W_FF_G], HD, HD);
+  if ((rc = mm(st, F(L.bF1), HD, T[ENF_W_FF_BE], HD, T[ENF_W_FF_W1], HD, 1, HD, HD, 1.f, T[ENF_W_FF_B1], 0))) return rc;
+  CK(cp(L.bO0, T[ENF_W_O0_B], D)); CK(cp(L.bO2, T[ENF_W_O2_B], D));
+  hipLaunchKernelGGL(padcopy_kernel, dim3((OP + 127) / 128, 1), dim3(128), 0, st, F(L.bO4), T[ENF_W_O4_B], 1, O, OP);
+  hipLaunchKernelGGL(padcopy_kernel, dim3((OP + 127) / 128, D), dim3(128), 0, st, F(L.p_o4), T[ENF_W_O4_W], D, O, OP);
+  if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
+  // ---- forward panels: A[out][in] = W[in][out]
+  const int bf = m.bf16;
+  if ((rc = pack_panel(st, blob, L.aq1, T[ENF_W_RQ_W1], D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.av1, T[ENF_W_RV_W1], D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.af, F(L.p_af), D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.agb, F(L.p_agb), 2 * HD, 2 * HD, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.am, T[ENF_W_MX_W0], D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.atb, F(L.p_wb), HD, HD, HD, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.atf1, F(L.p_wf1), HD, HD, HD, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.ato0, T[ENF_W_O0_W], D, D, HD, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.ato2, T[ENF_W_O2_W], D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.ato4, F(L.p_o4), OP, OP, D, 0, bf))) return rc;
+  // ---- backward panels: A[in][out] = W[in][out]   (dX = W dY)
+  if ((rc = pack_panel(st, blob, L.gq1, T[ENF_W_RQ_W1], D, D, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gv1, T[ENF_W_RV_W1], D, D, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gf, F(L.p_af), D, D, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.ggb, F(L.p_agb), 2 * HD, D, 2 * HD, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gm, T[ENF_W_MX_W0], D, D, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gtb, F(L.p_wb), HD, HD, HD, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gtf1, F(L.p_wf1), HD, HD, HD, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gto0, T[ENF_W_O0_W], D, HD, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gto2, T[ENF_W_O2_W], D, D, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gto4, F(L.p_o4), OP, D, OP, 1, bf))) return rc;
+  return ENF_OK;
+}
+
+// ---------------------------------------------------------------- K1 latent prologue
+constexpr int ZT = 8;  // latents per block: every weight element is read once per 8 latents
+
+static __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nthreads) {
+  // sum over the block (nthreads multiple of 64, <= 256); red: 8 floats of LDS
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < nthreads / 64; ++w) s += red[w];
+  return s;
+}
+
+struct PrologueArgs {
+  const float* p; const float* a; const float* sigma;
+  const char* blob; EnfLayout L;
+  float* lt; float* an; float* kv;
+  int BZ, H, D, C, dp, inv;
+};
+
+// one block = ZT consecutive (b,z) rows; 256 threads
+__global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
+  extern __shared__ float sm[];
+  const int D = A.D, H = A.H, HD = H * D, C = A.C;
+  float* s_a = sm;                 // ZT x C
+  float* s_an = s_a + ZT * C;      // ZT x D
+  float* s_k = s_an + ZT * D;      // ZT x HD
+  float* s_red = s_k + ZT * HD;    // 8
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * ZT;
+  auto W = [&](size_t off) { return reinterpret_cast<const float*>(A.blob + off); };
+  const int stride = enf_lt_stride(H, D);
+  for (int i = tid; i < ZT * C; i += 256) {
+    const int r = row0 + i / C;
+    s_a[i] = r < A.BZ ? A.a[(size_t)r * C + i % C] : 0.f;
+  }
+  __syncthreads();
+  // stem: s = a @ Ws + bs  (NEF:220)
+  for (int d = tid; d < D; d += 256) {
+    float acc[ZT];
+    const float bs = W(A.L.stem_b)[d];
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) acc[zz] = bs;
+    for (int c = 0; c < C; ++c) {
+      const float w = W(A.L.stem_w)[(size_t)c * D + d];
+#pragma unroll
+      for (int zz = 0; zz < ZT; ++zz) acc[zz] = fmaf(s_a[zz * C + c], w, acc[zz]);
+    }
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) s_an[zz * D + d] = acc[zz];
+  }
+  __syncthreads();
+  // LayerNorm (NEF:56): biased variance, eps 1e-6
+  for (int zz = 0; zz < ZT; ++zz) {
+    const int r = row0 + zz;
+    float v = 0.f;
+    for (int d = tid; d < D; d += 256) v += s_an[zz * D + d];
+    const float mu = block_sum(v, s_red, tid, 256) / D;
+    float q = 0.f;
+    for (int d = tid; d < D; d += 256) { const float t = s_an[zz * D + d] - mu; q += t * t; }
+    const float var = block_sum(q, s_red, tid, 256) / D;
+    const float rstd = rsqrtf(var + 1e-6f);
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) {
+      const float s = s_an[zz * D + d];
+      const float xn = (s - mu) * rstd;
+      if (r < A.BZ) {
+        A.an[(size_t)r * (2 * D + 2) + d] = s;           // stem output (pre-LN)
+        A.an[(size_t)r * (2 * D + 2) + D + d] = xn;      // normalised, before scale/bias
+      }
+      s_an[zz * D + d] = xn * W(A.L.lna_g)[d] + W(A.L.lna_b)[d];
+    }
+    if (tid == 0 && r < A.BZ) { A.an[(size_t)r * (2 * D + 2) + 2 * D] = mu; A.an[(size_t)r * (2 * D + 2) + 2 * D + 1] = rstd; }
+  }
+  __syncthreads();
+  // k = an @ Wk + bk, v0 = an @ Wv + bv   (ECA:93-94)
+  for (int j = tid; j < 2 * HD; j += 256) {
+    const bool isv = j >= HD;
+    const int jj = isv ? j - HD : j;
+    const float* Wm = W(isv ? A.L.wv : A.L.wk);
+    float acc[ZT];
+    const float bb = W(isv ? A.L.bv : A.L.bk)[jj];
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) acc[zz] = bb;
+    for (int d = 0; d < D; ++d) {
+      const float w = Wm[(size_t)d * HD + jj];
+#pragma unroll
+      for (int zz = 0; zz < ZT; ++zz) acc[zz] = fmaf(s_an[zz * D + d], w, acc[zz]);
+    }
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) {
+      const int r = row0 + zz;
+      if (!isv) s_k[zz * HD + jj] = acc[zz];
+      if (r < A.BZ) {
+        A.kv[(size_t)r * 2 * HD + j] = acc[zz];
+        if (isv) A.lt[(size_t)r * stride + enf_lt_off_v0(H, D) + jj] = acc[zz];
+      }
+    }
+  }
+  __syncthreads();
+  // u_h = MU_h k_h ; c_h = cvec_h . k_h
+  for (int j = tid; j < HD; j += 256) {
+    const int h = j / D, i = j % D;
+    const float* mu = W(A.L.mu) + ((size_t)h * D + i) * D;
+    float acc[ZT];
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) acc[zz] = 0.f;
+    for (int dd = 0; dd < D; ++dd) {
+      const float w = mu[dd];
+#pragma unroll
+      for (int zz = 0; zz < ZT; ++zz) acc[zz] = fmaf(w, s_k[zz * HD + h * D + dd], acc[zz]);
+    }
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) {
+      const int r = row0 + zz;
+      if (r < A.BZ) A.lt[(size_t)r * stride + enf_lt_off_u(H, D) + j] = acc[zz];
+    }
+  }
+  for (int t = tid; t < ZT * H; t += 256) {
+    const int zz = t / H, h = t % H, r = row0 + zz;
+    float s = 0.f;
+    for (int dd = 0; dd < D; ++dd) s = fmaf(W(A.L.cvec)[h * D + dd], s_k[zz * HD + h * D + dd], s);
+    if (r < A.BZ) A.lt[(size_t)r * stride + enf_lt_off_c(H, D) + h] = s;
+  }
+  // pose embed (NEF:214-217) + window coefficient
+  if (tid < ZT) {
+    const int r = row0 + tid;
+    if (r < A.BZ) {
+      const float* pp = A.p + (size_t)r * A.dp;
+      float q[4] = {0.f, 0.f, 0.f, 0.f};
+      float wc;
+      const float sg = A.sigma ? A.sigma[r] : 1.f;
+      if (A.inv == ENF_INV_PONITA) { q[0] = pp[0]; q[1] = pp[1]; q[2] = cosf(pp[2]); q[3] = sinf(pp[2]); }
+      else if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) {
+        q[0] = pp[0]; q[1] = pp[1]; q[2] = sinf(pp[1]); q[3] = cosf(pp[1]);
+      } else { for (int i = 0; i < A.dp && i < 3; ++i) q[i] = pp[i]; }
+      if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) wc = 1.f / (2.f * sg * sg);
+      else wc = 1.f / (sg * sg);
+      float* o = A.lt + (size_t)r * stride;
+      for (int i = 0; i < 4; ++i) o[enf_lt_off_pose(H, D) + i] = q[i];
+      o[enf_lt_off_wcoef(H, D)] = wc;
+    }
+  }
+}
+
+extern "C" int enf_launch_prologue(const EnfDims& m, const EnfLayout& L, const char* blob, const float* p, const float* a,
+                                   const float* sigma, float* lt, float* an, float* kv, hipStream_t st) {
+  PrologueArgs A;
+  A.p = p; A.a = a; A.sigma = sigma; A.blob = blob; A.L = L; A.lt = lt; A.an = an; A.kv = kv;
+  A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp = m.dp; A.inv = m.inv;
+  const size_t smem = sizeof(float) * (ZT * m.C + ZT * m.D + ZT * m.HD + 8);
+  hipLaunchKernelGGL(enf_prologue_kernel, dim3((A.BZ + ZT - 1) / ZT), dim3(256), smem, st, A);
+  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+}
+
+// ---------------------------------------------------------------- K1 backward
+// dlt (B*Z rows: du | dv0 | dc | dpose | dwcoef) -> dp, da, dsigma
+struct PrologueBwdArgs {
+  const float* p; const float* sigma; const char* blob; EnfLayout L;
+  const float* an; const float* kv; const float* dlt;
+  float* dp; float* da; float* dsigma;
+  int BZ, H, D, C, dp_dim, inv;
+};
+
+__global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A) {
+  extern __shared__ float sm[];
+  const int D = A.D, H = A.H, HD = H * D, C = A.C;
+  float* s_dk = sm;               // ZT x 2HD  (dk | dv0)
+  float* s_dan = s_dk + ZT * 2 * HD;  // ZT x D
+  float* s_red = s_dan + ZT * D;  // 8
+  const int tid = threadIdx.x, row0 = blockIdx.x * ZT;
+  const int stride = enf_lt_stride(H, D);
+  auto W = [&](size_t off) { return reinterpret_cast<const float*>(A.blob + off); };
+  // dk[h*D+d] = sum_i MU_h[i][d] du_h[i] + cvec_h[d] dc_h ; dv0 passes through
+  for (int j = tid; j < HD; j += 256) {
+    const int h = j / D, dd = j % D;
+    float acc[ZT];
+    const float cv = W(A.L.cvec)[h * D + dd];
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) {
+      const int r = row0 + zz;
+      acc[zz] = r < A.BZ ? cv * A.dlt[(size_t)r * stride + enf_lt_off_c(H, D) + h] : 0.f;
+    }
+    for (int i = 0; i < D; ++i) {
+      const float w = W(A.L.mu)[((size_t)h * D + i) * D + dd];
+#pragma unroll
+      for (int zz = 0; zz < ZT; ++zz) {
+        const int r = row0 + zz;
+        const float du = r < A.BZ ? A.dlt[(size_t)r * stride + enf_lt_off_u(H, D) + h * D + i] : 0.f;
+        acc[zz] = fmaf(w, du, acc[zz]);
+      }
+    }
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) {
+      const int r = row0 + zz;
+      s_dk[zz * 2 * HD + j] = acc[zz];
+      s_dk[zz * 2 * HD + HD + j] = r < A.BZ ? A.dlt[(size_t)r * stride + enf_lt_off_v0(H, D) + j] : 0.f;
+    }
+  }
+  __syncthreads();
+  // d(an_affine)[d] = sum_j Wk[d][j] dk[j] + Wv[d][j] dv0[j]; then through scale: dxn = dy * g
+  for (int d = tid; d < D; d += 256) {
+    float acc[ZT];
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) acc[zz] = 0.f;
+    for (int j = 0; j < HD; ++j) {
+      const float wk = W(A.L.wk)[(size_t)d * HD + j], wv = W(A.L.wv)[(size_t)d * HD + j];
+#pragma unroll
+      for (int zz = 0; zz < ZT; ++zz)
+        acc[zz] = fmaf(wk, s_dk[zz * 2 * HD + j], fmaf(wv, s_dk[zz * 2 * HD + HD + j], acc[zz]));
+    }
+    const float g = W(A.L.lna_g)[d];
+#pragma unroll
+    for (int zz = 0; zz < ZT; ++zz) s_dan[zz * D + d] = acc[zz] * g;
+  }
+  __syncthreads();
+  // LayerNorm backward: ds = rstd * (dxn - mean(dxn) - xn * mean(dxn * xn))
+  for (int zz = 0; zz < ZT; ++zz) {
+    const int r = row0 + zz;
+    const int rr = r < A.BZ ? r : A.BZ - 1;
+    const float* anr = A.an + (size_t)rr * (2 * D + 2);
+    float v1 = 0.f, v2 = 0.f;
+    for (int d = tid; d < D; d += 256) { const float g = s_dan[zz * D + d]; v1 += g; v2 += g * anr[D + d]; }
+    const float m1 = block_sum(v1, s_red, tid, 256) / D;
+    const float m2 = block_sum(v2, s_red, tid, 256) / D;
+    const float rstd = anr[2 * D + 1];
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) s_dan[zz * D + d] = rstd * (s_dan[zz * D + d] - m1 - anr[D + d] * m2);
+  }
+  __syncthreads();
+  // da[c] = sum_d Ws[c][d] ds[d]
+  for (int t = tid; t < ZT * C; t += 256) {
+    const int zz = t / C, c = t % C, r = row0 + zz;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(W(A.L.stem_w)[(size_t)c * D + d], s_dan[zz * D + d], s);
+    if (r < A.BZ) A.da[(size_t)r * C + c] = s;
+  }
+  if (tid < ZT) {
+    const int r = row0 + tid;
+    if (r < A.BZ) {
+      const float* g = A.dlt + (size_t)r * stride + enf_lt_off_pose(H, D);
+      const float* pp = A.p + (size_t)r * A.dp_dim;
+      float* o = A.dp + (size_t)r * A.dp_dim;
+      if (A.inv == ENF_INV_PONITA) { o[0] = g[0]; o[1] = g[1]; o[2] = -sinf(pp[2]) * g[2] + cosf(pp[2]) * g[3]; }
+      else if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) {
+        o[0] = g[0]; o[1] = g[1] + cosf(pp[1]) * g[2] - sinf(pp[1]) * g[3];
+      } else { for (int i = 0; i < A.dp_dim && i < 3; ++i) o[i] = g[i]; }
+      const float sg = A.sigma ? A.sigma[r] : 1.f;
+      const float dwc = A.dlt[(size_t)r * stride + enf_lt_off_wcoef(H, D)];
+      const bool sph = A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC;
+      A.dsigma[r] = (sph ? -1.f : -2.f) / (sg * sg * sg) * dwc;
+    }
+  }
+}
+
+extern "C" int enf_launch_prologue_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* p,
+                                       const float* sigma, const float* an, const float* kv, const float* dlt, float* dp,
+                                       float* da, float* dsigma, hipStream_t st) {
+  PrologueBwdArgs A;
+  A.p = p; A.sigma = sigma; A.blob = blob; A.L = L; A.an = an; A.kv = kv; A.dlt = dlt;
+  A.dp = dp; A.da = da; A.dsigma = dsigma;
+  A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp_dim = m.dp; A.inv = m.inv;
+  const size_t smem = sizeof(float) * (ZT * 2 * m.HD + ZT * m.D + 8);
+  hipLaunchKernelGGL(enf_prologue_bwd_kernel, dim3((A.BZ + ZT - 1) / ZT), dim3(256), smem, st, A);
+  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+}

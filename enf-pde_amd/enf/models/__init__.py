@@ -1,0 +1,309 @@
+"""EquivariantCrossAttentionNeF -- host-side mirror of enf/models/equivariant_cross_attention_nef.py:70-235.
+
+Same constructor keywords (experiments/fitting/__init__.py:25-38), same ``init`` / ``apply``
+call shapes as the Flax module, same parameter tree (names follow Flax's naming rules, SURVEY.md
+8a), same latent conventions.  ``apply`` runs the fused HIP path through the C-ABI
+(include/enf_hip.h); gradients w.r.t. the latents (p, a, gaussian_window) come from the
+hand-written HIP backward.  There is no eager / CPU path.
+"""
+import ctypes
+import math
+
+import torch
+
+from .. import steerable_attention  # noqa: F401  (package layout parity)
+from ..steerable_attention.invariant import BaseInvariant
+from ... import _lib
+
+__all__ = ["EquivariantCrossAttentionNeF", "TENSOR_PATHS"]
+
+_BLK = "cross_attention_blocks_0"
+# ENF_W_* order of include/enf_hip.h -> path in the Flax parameter tree
+TENSOR_PATHS = [
+    ("latent_stem", "kernel"), ("latent_stem", "bias"),
+    (_BLK, "layer_norm_attn", "scale"), (_BLK, "layer_norm_attn", "bias"),
+    (_BLK, "attn", "invariant_embedding_query", "encoding", "coefficients"),
+    (_BLK, "attn", "invariant_embedding_query", "layers_0", "linear", "kernel"),
+    (_BLK, "attn", "invariant_embedding_query", "layers_0", "linear", "bias"),
+    (_BLK, "attn", "invariant_embedding_query", "linear_final", "kernel"),
+    (_BLK, "attn", "invariant_embedding_query", "linear_final", "bias"),
+    (_BLK, "attn", "invariant_embedding_value", "encoding", "coefficients"),
+    (_BLK, "attn", "invariant_embedding_value", "layers_0", "linear", "kernel"),
+    (_BLK, "attn", "invariant_embedding_value", "layers_0", "linear", "bias"),
+    (_BLK, "attn", "invariant_embedding_value", "linear_final", "kernel"),
+    (_BLK, "attn", "invariant_embedding_value", "linear_final", "bias"),
+    (_BLK, "attn", "inv_emb_to_q", "kernel"), (_BLK, "attn", "inv_emb_to_q", "bias"),
+    (_BLK, "attn", "a_to_k", "kernel"), (_BLK, "attn", "a_to_k", "bias"),
+    (_BLK, "attn", "a_to_v", "kernel"), (_BLK, "attn", "a_to_v", "bias"),
+    (_BLK, "attn", "inv_emb_to_v", "Dense_0", "kernel"), (_BLK, "attn", "inv_emb_to_v", "Dense_0", "bias"),
+    (_BLK, "attn", "inv_emb_to_v", "LayerNorm_0", "scale"), (_BLK, "attn", "inv_emb_to_v", "LayerNorm_0", "bias"),
+    (_BLK, "attn", "inv_emb_to_v", "Dense_1", "kernel"), (_BLK, "attn", "inv_emb_to_v", "Dense_1", "bias"),
+    (_BLK, "attn", "inv_emb_cond_mixer", "Dense_0", "kernel"), (_BLK, "attn", "inv_emb_cond_mixer", "Dense_0", "bias"),
+    (_BLK, "attn", "inv_emb_cond_mixer", "LayerNorm_0", "scale"), (_BLK, "attn", "inv_emb_cond_mixer", "LayerNorm_0", "bias"),
+    (_BLK, "attn", "inv_emb_cond_mixer", "Dense_1", "kernel"), (_BLK, "attn", "inv_emb_cond_mixer", "Dense_1", "bias"),
+    (_BLK, "attn", "out_proj", "kernel"), (_BLK, "attn", "out_proj", "bias"),
+    (_BLK, "pointwise_ffn", "Dense_0", "kernel"), (_BLK, "pointwise_ffn", "Dense_0", "bias"),
+    (_BLK, "pointwise_ffn", "LayerNorm_0", "scale"), (_BLK, "pointwise_ffn", "LayerNorm_0", "bias"),
+    (_BLK, "pointwise_ffn", "Dense_1", "kernel"), (_BLK, "pointwise_ffn", "Dense_1", "bias"),
+    ("out_proj", "layers_0", "kernel"), ("out_proj", "layers_0", "bias"),
+    ("out_proj", "layers_2", "kernel"), ("out_proj", "layers_2", "bias"),
+    ("out_proj", "layers_4", "kernel"), ("out_proj", "layers_4", "bias"),
+]
+assert len(TENSOR_PATHS) == _lib.ENF_NUM_TENSORS
+
+
+def _get(tree, path):
+    for k in path:
+        tree = tree[k]
+    return tree
+
+
+def _set(tree, path, value):
+    for k in path[:-1]:
+        tree = tree.setdefault(k, {})
+    tree[path[-1]] = value
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class _EnfFunction(torch.autograd.Function):
+    """nef.apply with the HIP forward (enf_forward) and backward-to-latents (enf_backward_latents)."""
+
+    @staticmethod
+    def forward(ctx, x, p, a, sigma, model, packed):
+        lib = _lib.load()
+        B, Z = p.shape[0], p.shape[1]
+        N = x.shape[1]
+        desc = model._desc(B, N, Z)
+        xb, xstride = model._x_arg(x)
+        p_, a_ = p.contiguous(), a.contiguous()
+        s_ = sigma.contiguous() if sigma is not None else None
+        dev = p.device
+        out = torch.empty((B, N, model.num_out), device=dev, dtype=torch.float32)
+        HD = model.num_heads * model.num_hidden
+        ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
+        lse = torch.empty((B, N, model.num_heads), device=dev, dtype=torch.float32)
+        ws = model._workspace(desc, dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.enf_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
+                                   _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), st))
+        ctx.model = model
+        ctx.has_sigma = sigma is not None
+        ctx.xstride = xstride
+        ctx.save_for_backward(xb, p_, a_, s_ if s_ is not None else p_.new_empty(0), packed, ybar, lse)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        lib = _lib.load()
+        model = ctx.model
+        xb, p_, a_, s_, packed, ybar, lse = ctx.saved_tensors
+        sigma = s_ if ctx.has_sigma else None
+        B, Z = p_.shape[0], p_.shape[1]
+        N = ybar.shape[1]
+        desc = model._desc(B, N, Z)
+        dev = p_.device
+        dout = dout.contiguous().float()
+        dp = torch.empty_like(p_)
+        da = torch.empty_like(a_)
+        dsig = torch.empty((B, Z, 1), device=dev, dtype=torch.float32)
+        ws = model._workspace(desc, dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.enf_backward_latents(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(p_), _ptr(a_), _ptr(sigma),
+                                            _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
+                                            _ptr(dsig), _ptr(ws), ws.numel(), st))
+        return None, dp, da, (dsig if ctx.has_sigma else None), None, None
+
+
+class EquivariantCrossAttentionNeF:
+    """Equivariant cross-attention neural field (NEF:70-235) on the fused gfx950 path.
+
+    Args mirror the Flax module's fields (NEF:85-96); ``precision`` ("bf16" | "f32") selects
+    the MFMA arithmetic of the per-pair contractions (ENF_PREC_*).
+    """
+
+    def __init__(self, num_hidden, num_heads, num_layers, num_out, latent_dim, cross_attn_invariant,
+                 self_attn_invariant=None, embedding_type="rff", embedding_freq_multiplier=(0.05, 0.1),
+                 condition_value_transform=True, use_gaussian_window=True, precision="bf16"):
+        if not isinstance(cross_attn_invariant, BaseInvariant):
+            raise TypeError("cross_attn_invariant must come from enf.steerable_attention.invariant.get_ca_invariant")
+        if embedding_type != "rff":
+            if embedding_type in ("ffn", "polynomial"):
+                raise NotImplementedError(f"embedding type '{embedding_type}' is outside the accelerated path "
+                                          "(no shipped config selects it; SURVEY.md 2, row 2)")
+            raise ValueError(f"Unknown embedding type: {embedding_type}.")          # EMB:33
+        if num_layers != 0:
+            raise NotImplementedError("latent self-attention layers (num_layers > 0) are not on the accelerated "
+                                      "path: every shipped config runs num_layers=0 (SURVEY.md 0.3)")
+        if not condition_value_transform:
+            raise NotImplementedError("condition_value_transform=False is not on the accelerated path")
+        assert not num_hidden % 2, "For the Fourier Features hidden_dim should be even to calculate them correctly."  # RFF:75-77
+        if precision not in _lib.PREC:
+            raise ValueError(f"unknown precision {precision!r}")
+        self.num_hidden, self.num_heads, self.num_layers = int(num_hidden), int(num_heads), int(num_layers)
+        self.num_out, self.latent_dim = int(num_out), int(latent_dim)
+        self.cross_attn_invariant = cross_attn_invariant
+        self.self_attn_invariant = self_attn_invariant if self_attn_invariant is not None else cross_attn_invariant
+        self.embedding_type = embedding_type
+        self.embedding_freq_multiplier = tuple(embedding_freq_multiplier)
+        self.condition_value_transform = condition_value_transform
+        self.use_gaussian_window = bool(use_gaussian_window)
+        self.precision = precision
+        self._pack_cache = {}
+        self._ws_cache = {}
+
+    # ------------------------------------------------------------------ descriptors / buffers
+    def _desc(self, B, N, Z):
+        inv = self.cross_attn_invariant
+        return _lib.make_desc(B, N, Z, self.num_heads, self.num_hidden, self.latent_dim, self.num_out,
+                              inv.num_x_pos_dims, inv.kernel_id, self.use_gaussian_window, _lib.PREC[self.precision])
+
+    def _workspace(self, desc, device):
+        # one cached scratch buffer per (shape, stream); the autograd graph never keeps it alive
+        lib = _lib.load()
+        nbytes = lib.enf_workspace_bytes(ctypes.byref(desc))
+        if nbytes == 0:
+            _lib.check(lib.enf_check_desc(ctypes.byref(desc)))
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws_cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+            self._ws_cache[key] = ws
+        return ws
+
+    @staticmethod
+    def _x_arg(x):
+        """(tensor to pass, batch stride in elements); a stride-0 batch (broadcast grid) is legal (TR:197,393)."""
+        if x.dim() != 3:
+            raise ValueError("x must be (batch, num_coords, coord_dim)")
+        if x.stride(0) == 0:
+            return x[0].contiguous(), 0
+        xc = x.contiguous()
+        return xc, xc.shape[1] * xc.shape[2]
+
+    # ------------------------------------------------------------------ parameters
+    def init(self, key, x=None, p=None, a=None, gaussian_window_size=None, device=None):
+        """Random parameters with the reference's initialisers.  ``key`` is an int
+        seed or a torch.Generator (JAX PRNG keys cannot be reproduced).  The sample inputs are
+        accepted for call-shape parity with ``nef.init(key, x, p, a, window)`` (TR:101) and only
+        supply the device."""
+        if device is None:
+            device = p.device if p is not None else torch.device("cuda")
+        g = key if isinstance(key, torch.Generator) else torch.Generator().manual_seed(int(key))
+        D, H, C, O = self.num_hidden, self.num_heads, self.latent_dim, self.num_out
+        I = self.cross_attn_invariant.dim
+        HD = H * D
+
+        def normal(shape, std):
+            return torch.randn(shape, generator=g) * std
+
+        def lecun(n_in, n_out):     # flax Dense default: truncated normal, std sqrt(1/fan_in) / .8796
+            t = torch.empty(n_in, n_out)
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
+            return {"kernel": t * (math.sqrt(1.0 / n_in) / 0.87962566103423978), "bias": torch.zeros(n_out)}
+
+        def ln(n):
+            return {"scale": torch.ones(n), "bias": torch.zeros(n)}
+
+        def ffn(n_in, n_hid, n_out):
+            return {"Dense_0": lecun(n_in, n_hid), "LayerNorm_0": ln(n_hid), "Dense_1": lecun(n_hid, n_out)}
+
+        def rff(std):
+            lim = math.sqrt(3 * 2.0 / D)
+            return {"encoding": {"coefficients": normal((I, D // 2), std)},                                   # RFF:83
+                    "layers_0": {"linear": {"kernel": normal((D, D), math.sqrt(2.0 / D)), "bias": normal((D,), 1e-6)}},  # RFF:55-60
+                    "linear_final": {"kernel": (torch.rand((D, D), generator=g) * 2 - 1) * lim, "bias": normal((D,), 1e-6)}}  # RFF:35-40
+
+        fq, fv = self.embedding_freq_multiplier
+        attn = {"invariant_embedding_query": rff(fq), "invariant_embedding_value": rff(fv),
+                "inv_emb_to_q": lecun(D, HD), "a_to_k": lecun(D, HD), "a_to_v": lecun(D, HD),
+                "inv_emb_to_v": ffn(D, D, 2 * HD), "inv_emb_cond_mixer": ffn(D, D, D), "out_proj": lecun(HD, HD)}
+        P = {"latent_stem": lecun(C, D),
+             _BLK: {"layer_norm_attn": ln(D), "attn": attn, "pointwise_ffn": ffn(HD, HD, HD)},
+             "out_proj": {"layers_0": lecun(HD, D), "layers_2": lecun(D, D), "layers_4": lecun(D, O)}}
+
+        def to_dev(t):
+            return {k: to_dev(v) for k, v in t.items()} if isinstance(t, dict) else t.to(device=device, dtype=torch.float32)
+        return {"params": to_dev(P)}
+
+    def param_tensors(self, params):
+        """The ENF_NUM_TENSORS weight tensors in C-ABI order."""
+        P = params["params"] if "params" in params else params
+        return [_get(P, path) for path in TENSOR_PATHS]
+
+    def load_params(self, tree, device="cuda"):
+        """Build a parameter tree from nested numpy / torch arrays (e.g. an exported Flax tree)."""
+        P = tree["params"] if "params" in tree else tree
+        out = {}
+        for path in TENSOR_PATHS:
+            _set(out, path, torch.as_tensor(_get(P, path)).to(device=device, dtype=torch.float32).contiguous())
+        return {"params": out}
+
+    def pack(self, params):
+        """Packed weight blob (device uint8 tensor) for ``params``; cached until a tensor changes."""
+        lib = _lib.load()
+        ts = self.param_tensors(params)
+        dev = ts[0].device
+        if dev.type != "cuda":
+            raise _lib.EnfError("parameters must live on the GPU: the decoder has no CPU path")
+        key = (self.precision, tuple((t.data_ptr(), t._version) for t in ts))
+        hit = self._pack_cache.get("k")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        desc = self._desc(1, 1, 1)
+        _lib.check(lib.enf_check_desc(ctypes.byref(desc)))
+        shapes = self._expected_shapes()
+        ts = [t.detach().to(torch.float32).contiguous() for t in ts]
+        for t, shp, path in zip(ts, shapes, TENSOR_PATHS):
+            if tuple(t.shape) != shp:
+                raise ValueError(f"parameter {'/'.join(path)} has shape {tuple(t.shape)}, expected {shp}")
+        nbytes = lib.enf_packed_weight_bytes(ctypes.byref(desc))
+        blob = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+        arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.enf_pack_weights(ctypes.byref(desc), arr, _ptr(blob), st))
+        self._pack_cache["k"] = (key, blob, ts)   # keep the fp32 sources alive until the pack kernels ran
+        return blob
+
+    def _expected_shapes(self):
+        D, H, C, O, I = self.num_hidden, self.num_heads, self.latent_dim, self.num_out, self.cross_attn_invariant.dim
+        HD = H * D
+        rff = [(I, D // 2), (D, D), (D,), (D, D), (D,)]
+        return ([(C, D), (D,), (D,), (D,)] + rff + rff + [(D, HD), (HD,)] * 3 +
+                [(D, D), (D,), (D,), (D,), (D, 2 * HD), (2 * HD,)] + [(D, D), (D,), (D,), (D,), (D, D), (D,)] +
+                [(HD, HD), (HD,)] + [(HD, HD), (HD,), (HD,), (HD,), (HD, HD), (HD,)] +
+                [(HD, D), (D,), (D, D), (D,), (D, O), (O,)])
+
+    # ------------------------------------------------------------------ forward
+    def apply(self, params, x, p, a, gaussian_window_size=None):
+        """nef.apply(params, x, p, a, gaussian_window) -> (B, N, num_out)   (NEF:204-235).
+
+        x (B,N,dx) [stride-0 batch allowed], p (B,Z,z_pos+z_ori), a (B,Z,latent_dim),
+        gaussian_window_size (B,Z,1).  Differentiable w.r.t. p, a, gaussian_window_size.
+        """
+        inv = self.cross_attn_invariant
+        if not (x.is_cuda and p.is_cuda and a.is_cuda):
+            raise _lib.EnfError("EquivariantCrossAttentionNeF.apply needs CUDA/HIP tensors: there is no CPU path")
+        if x.shape[-1] != inv.num_x_pos_dims:
+            raise AssertionError(f"x has coordinate width {x.shape[-1]}, invariant '{inv.name}' expects {inv.num_x_pos_dims}")
+        if p.shape[-1] != inv.num_z_pos_dims + inv.num_z_ori_dims:
+            raise AssertionError(f"p has width {p.shape[-1]}, expected {inv.num_z_pos_dims + inv.num_z_ori_dims}")
+        if a.shape[-1] != self.latent_dim:
+            raise AssertionError(f"a has width {a.shape[-1]}, expected latent_dim={self.latent_dim}")
+        if x.shape[0] != p.shape[0] or a.shape[:2] != p.shape[:2]:
+            raise AssertionError("batch / latent dimensions of x, p, a disagree")
+        sigma = gaussian_window_size if self.use_gaussian_window else None
+        if self.use_gaussian_window and sigma is None:
+            raise AssertionError("gaussian_window_size is required when use_gaussian_window=True")
+        if sigma is not None and not torch.is_tensor(sigma):
+            sigma = torch.full((p.shape[0], p.shape[1], 1), float(sigma), device=p.device)
+        packed = self.pack(params)
+        x, p, a = x.float(), p.float(), a.float()
+        if sigma is not None:
+            sigma = sigma.float().reshape(p.shape[0], p.shape[1], 1)
+        return _EnfFunction.apply(x, p, a, sigma, self, packed)
+
+    __call__ = apply

@@ -1,0 +1,76 @@
+"""MAML inner loop and decode on the HIP path (trainers/pde_trainer.py:122-235, 389-405)."""
+import torch
+
+
+def default_meta_sgd_lrs(latent_dim, lr_p=1.0, lr_a=5.0, lr_window=0.0, with_ori=False, device="cuda"):
+    """Initial inner learning rates (pde_trainer.py:83-97): scalar for poses/window, (C,) for a."""
+    lrs = {"p_pos": torch.full((1,), lr_p, device=device), "a": torch.full((latent_dim,), lr_a, device=device),
+           "gaussian_window": torch.full((1,), lr_window, device=device)}
+    if with_ori:
+        lrs["p_ori"] = torch.full((1,), lr_p, device=device)
+    return lrs
+
+
+def make_masks(num_coords, num_sampled, num_inner_steps, generator=None, device="cuda"):
+    """(N_s, S+1) independent column permutations truncated to N_s rows (pde_trainer.py:148-154).
+    jax.random.permutation cannot be reproduced; parity tests pass masks explicitly."""
+    cols = [torch.randperm(num_coords, generator=generator)[:num_sampled] for _ in range(num_inner_steps + 1)]
+    return torch.stack(cols, dim=1).to(device)
+
+
+def _pose(lat, num_ori_dims):
+    return torch.cat((lat["p_pos"], lat["p_ori"]), dim=-1) if num_ori_dims > 0 else lat["p_pos"]
+
+
+def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaussian_window=False,
+               noise_pos=0.0, generator=None):
+    """Fit per-signal latents with S steps of meta-SGD (pde_trainer.py:156-235).
+
+    latents0 : {'p_pos','a','gaussian_window'[,'p_ori']} with leading dim 1 (the meta-init)
+    lrs      : inner learning rates, same keys
+    coords   : (N, dx) grid;  img: (B, N, O) targets;  masks: (N_s, S+1) long
+    Each step is one HIP forward + one HIP backward-to-latents; the gradient of the batch-mean
+    loss is multiplied by B (pde_trainer.py:207) so signals are independent.
+    Returns (loss on the last mask, fitted latents dict with leading dim B).
+    """
+    B = img.shape[0]
+    S = masks.shape[1] - 1
+    n_ori = nef.cross_attn_invariant.num_z_ori_dims
+    lat = {k: v.detach().repeat_interleave(B, dim=0).clone() for k, v in latents0.items()}   # pde_trainer.py:157-159
+    if noise_pos:                                                                             # pde_trainer.py:162-167
+        lat["p_pos"] = lat["p_pos"] + torch.randn(lat["p_pos"].shape, generator=generator,
+                                                  device="cpu").to(lat["p_pos"].device) * noise_pos
+
+    def loss_fn(lat, s):
+        xs = coords[masks[:, s]][None].expand(B, -1, -1)                # stride-0 batch (pde_trainer.py:193-197)
+        ys = img[:, masks[:, s]]
+        out = nef.apply(nef_params, xs, _pose(lat, n_ori), lat["a"], lat["gaussian_window"])
+        return ((out - ys) ** 2).mean()                                 # pde_trainer.py:185
+
+    for s in range(S):                                                  # pde_trainer.py:191
+        leaves = {k: v.detach().requires_grad_(True) for k, v in lat.items()}
+        keys = [k for k in leaves if not (k == "gaussian_window" and not nef.use_gaussian_window)]
+        grads = torch.autograd.grad(loss_fn(leaves, s), [leaves[k] for k in keys], allow_unused=True)
+        new = {}
+        for k in leaves:
+            g = dict(zip(keys, grads)).get(k)
+            g = torch.zeros_like(leaves[k]) if g is None else g * B                            # pde_trainer.py:207
+            if k == "gaussian_window" and not optimize_gaussian_window:                        # pde_trainer.py:210-212
+                g = torch.zeros_like(g)
+            new[k] = (leaves[k] - lrs[k] * g).detach()                                         # pde_trainer.py:215-219
+        lat = new
+    with torch.no_grad():
+        loss = loss_fn(lat, S)                                          # pde_trainer.py:225-235
+    return loss, lat
+
+
+@torch.no_grad()
+def decode(nef, nef_params, coords, p, a, window, chunk=None):
+    """Reconstruct (B, N, O) on the full grid (pde_trainer.py:393-402).  The fused kernel tiles over
+    queries itself, so ``chunk`` is optional (the reference chunks by max_num_sampled_points)."""
+    B = p.shape[0]
+    x = coords[None].expand(B, -1, -1) if coords.dim() == 2 else coords
+    if chunk is None:
+        return nef.apply(nef_params, x, p, a, window)
+    outs = [nef.apply(nef_params, x[:, i:i + chunk], p, a, window) for i in range(0, x.shape[1], chunk)]
+    return torch.cat(outs, dim=1)

@@ -1,0 +1,46 @@
+"""Meta-batch data parallelism: one process per GPU, signals sharded evenly,
+no data-path collective in fit/decode; the outer step exchanges ONE flat all-reduce (RCCL over
+xGMI on GPUs, gloo in CPU tests)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK/WORLD_SIZE/MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_range(num_items, rank, world):
+    """Contiguous, balanced [lo, hi) slice of ``num_items`` signals for ``rank`` (sizes differ by <= 1)."""
+    base, rem = divmod(num_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_mean_(tensors):
+    """Average a list of same-dtype tensors across ranks with ONE collective on a flat buffer
+    (2.1 MB of outer gradients is latency-bound on the xGMI ring: one message, not 50)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    return tensors

@@ -1,0 +1,126 @@
+/* enf_hip.h -- C-ABI of the MI355X (gfx950) Equivariant-Neural-Field decoder.
+ *
+ * The reference (david-knigge/enf-pde) exposes this path as a Flax module, not an FFI:
+ *   nef.apply(params, x, p, a, gaussian_window)            enf/models/equivariant_cross_attention_nef.py:204-235
+ *   jax.grad(loss)(latents)   (MAML inner step)            experiments/fitting/trainers/pde_trainer.py:175-200
+ * The entry points below are what a binding for that module would bind: one
+ * forward, one backward-to-latents, weight packing, and size queries.  Plain pointers and
+ * sizes only; every buffer is owned by the caller and lives in device (HBM) memory; nothing
+ * is allocated, freed or synchronised inside the library; all work is enqueued on `stream`
+ * (a hipStream_t passed as void*).  Functions return 0 or a negative ENF_E* code.
+ *
+ * Layouts (all fp32, C-contiguous, batch first):
+ *   x      (B, N, dx)   query coordinates; x_bstride = element stride between signals
+ *                       (0 = one grid broadcast over B, pde_trainer.py:197,393)
+ *   p      (B, Z, dp)   latent poses  (dp = z_pos + z_ori; ponita carries the raw angle,
+ *                       the cos/sin embed of NEF:214-217 happens inside)
+ *   a      (B, Z, C)    latent context codes
+ *   sigma  (B, Z, 1)    gaussian window size per latent
+ *   out    (B, N, O)
+ */
+#ifndef ENF_HIP_H
+#define ENF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENF_ABI_VERSION 1
+
+/* cross-attention invariants: enf/steerable_attention/invariant/__init__.py:47-78 */
+enum {
+  ENF_INV_REL_POS_PERIODIC = 0,  /* rel_pos_periodic.py:35-60,  window _base_invariant.py:35-43 */
+  ENF_INV_LATITUDE_PERIODIC = 1, /* spherical_longitude.py:57-85, window :34-55                  */
+  ENF_INV_POLAR_PERIODIC = 2,    /* polar_periodic.py:40-68,    window :35-38                    */
+  ENF_INV_PONITA = 3,            /* ponita.py:20-44 (PonitaPos2D), window _base_invariant.py:25-33 */
+  ENF_INV_ABS_POS = 4,           /* abs_pos.py:42                                                */
+  ENF_INV_REL_POS = 5,           /* rel_pos.py:41                                                */
+  ENF_INV_NORM_REL_POS = 6,      /* norm_rel_pos.py:34                                           */
+  ENF_INV_COUNT = 7
+};
+
+/* arithmetic of the per-pair contractions */
+enum {
+  ENF_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity mode) */
+  ENF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate (throughput mode) */
+};
+
+enum {
+  ENF_OK = 0,
+  ENF_EINVAL = -1,       /* NULL pointer / non-positive size */
+  ENF_EINVARIANT = -2,   /* unknown invariant id (reference: ValueError, invariant/__init__.py:78) */
+  ENF_EUNSUPPORTED = -3, /* shape outside the compiled kernel set (D in {64,128}, H in 1..4, ...) */
+  ENF_EWORKSPACE = -4,   /* workspace too small */
+  ENF_ELAUNCH = -5,      /* HIP launch error */
+  ENF_EDIM = -6          /* dx / dp inconsistent with the invariant (reference asserts, :62,65) */
+};
+
+typedef struct EnfDesc {
+  int32_t B, N, Z;       /* signals, queries per signal, latents per signal */
+  int32_t H, D, C, O;    /* num_heads, num_hidden, latent_dim, num_out (NEF:85-89) */
+  int32_t dx;            /* coordinate width (cfg.nef.num_in) */
+  int32_t invariant_id;  /* ENF_INV_* */
+  int32_t use_window;    /* use_gaussian_window (NEF:96) */
+  int32_t precision;     /* ENF_PREC_* */
+  int32_t reserved[5];
+} EnfDesc;
+
+/* Weight tensors in the order `enf_pack_weights` expects them; names are the Flax tree of
+ * EquivariantCrossAttentionNeF (SURVEY.md 8a "Weights"); kernels are (in, out), y = x@W + b. */
+enum {
+  ENF_W_STEM_W = 0, ENF_W_STEM_B,                 /* latent_stem                       NEF:134 */
+  ENF_W_LNA_G, ENF_W_LNA_B,                       /* cross_attention_blocks_0/layer_norm_attn NEF:29 */
+  ENF_W_RQ_COEF, ENF_W_RQ_W1, ENF_W_RQ_B1, ENF_W_RQ_W2, ENF_W_RQ_B2,  /* attn/invariant_embedding_query RFF:21-40 */
+  ENF_W_RV_COEF, ENF_W_RV_W1, ENF_W_RV_B1, ENF_W_RV_W2, ENF_W_RV_B2,  /* attn/invariant_embedding_value */
+  ENF_W_Q_W, ENF_W_Q_B,                           /* attn/inv_emb_to_q                 ECA:54 */
+  ENF_W_K_W, ENF_W_K_B,                           /* attn/a_to_k                       ECA:55 */
+  ENF_W_V_W, ENF_W_V_B,                           /* attn/a_to_v                       ECA:56 */
+  ENF_W_F1_W0, ENF_W_F1_B0, ENF_W_F1_G, ENF_W_F1_BE, ENF_W_F1_W1, ENF_W_F1_B1,  /* attn/inv_emb_to_v  ECA:65 */
+  ENF_W_MX_W0, ENF_W_MX_B0, ENF_W_MX_G, ENF_W_MX_BE, ENF_W_MX_W1, ENF_W_MX_B1,  /* attn/inv_emb_cond_mixer ECA:66 */
+  ENF_W_AO_W, ENF_W_AO_B,                         /* attn/out_proj                     ECA:72 */
+  ENF_W_FF_W0, ENF_W_FF_B0, ENF_W_FF_G, ENF_W_FF_BE, ENF_W_FF_W1, ENF_W_FF_B1,  /* pointwise_ffn     NEF:40-42 */
+  ENF_W_O0_W, ENF_W_O0_B, ENF_W_O2_W, ENF_W_O2_B, ENF_W_O4_W, ENF_W_O4_B,       /* out_proj layers_0/2/4 NEF:196-202 */
+  ENF_NUM_TENSORS
+};
+
+int enf_abi_version(void);
+const char* enf_strerror(int code);
+
+/* invariant metadata (mirrors BaseInvariant.dim / num_z_pos_dims / num_z_ori_dims, _base_invariant.py:7-23) */
+int enf_invariant_dim(int invariant_id, int dx);        /* I, or ENF_EINVARIANT */
+int enf_invariant_pose_dim(int invariant_id, int dx);   /* dp = z_pos + z_ori    */
+
+/* validate a descriptor against the compiled kernel set */
+int enf_check_desc(const EnfDesc* d);
+
+/* bytes of the packed weight blob (MFMA-fragment-ordered panels + folded matrices) */
+size_t enf_packed_weight_bytes(const EnfDesc* d);
+/* Build the packed blob from ENF_NUM_TENSORS device pointers (fp32).  Runs the exact
+ * algebraic folds of DESIGN.md ("folds") in fp32 on the device.  `tensors` is a host array. */
+int enf_pack_weights(const EnfDesc* d, const float* const* tensors, void* packed, void* stream);
+
+/* scratch the forward / backward need (latent table, per-query partials) */
+size_t enf_workspace_bytes(const EnfDesc* d);
+
+/* Replaces nef.apply (NEF:204-235).  `ybar` (B,N,H*D) and `lse` (B,N,H) are optional
+ * outputs (may be NULL): the attention-weighted value sum and the softmax log-sum-exp,
+ * which enf_backward_latents takes back instead of recomputing the forward. */
+int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
+                const float* sigma, const void* packed, float* out, float* ybar, float* lse,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces jax.grad(loss)(latents) for one inner step (pde_trainer.py:188,200): given
+ * dL/dout it returns dL/dp (B,Z,dp), dL/da (B,Z,C), dL/dsigma (B,Z,1).  Buffers are
+ * overwritten, not accumulated.  `ybar`/`lse` come from enf_forward on the same inputs. */
+int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p,
+                         const float* a, const float* sigma, const void* packed, const float* ybar,
+                         const float* lse, const float* dout, float* dp, float* da, float* dsigma,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENF_HIP_H */

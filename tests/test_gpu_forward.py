@@ -1,0 +1,63 @@
+"""Forward parity of the HIP path (through the C-ABI) against the fp64 numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import enf_ref_np as R
+from tests.helpers import make_cfg, make_inputs, build_nef
+
+pytestmark = pytest.mark.gpu
+
+# tolerances on max|err| / max|ref| : fp32 mode = exact-fp32 MFMA chain; bf16 mode = bf16 operands
+TOL = {"f32": 2e-5, "bf16": 3e-2}
+
+
+def run_case(cuda, cfg, B, N, Z, precision, seed=0, jitter=0.1, broadcast_x=False):
+    prm = R.init_params(seed, cfg, jitter=jitter)
+    x, p, a, s = make_inputs(cfg, B, N, Z, seed + 1)
+    if broadcast_x:
+        x = np.broadcast_to(x[:1], x.shape).copy()
+    ref = R.nef_apply(prm, cfg, x, p, a, s)
+    nef = build_nef(cfg, precision)
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    xt = t(x[0])[None].expand(B, -1, -1) if broadcast_x else t(x)
+    out = nef.apply(params, xt, t(p), t(a), t(s))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy().astype(np.float64)
+    assert np.isfinite(out).all()
+    err = np.abs(out - ref).max() / max(np.abs(ref).max(), 1e-6)
+    mse = ((out - ref) ** 2).mean()
+    return err, mse
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("invariant", ["rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos",
+                                       "rel_pos", "norm_rel_pos"])
+def test_forward_invariants(cuda, invariant, precision):
+    cfg = make_cfg(invariant, D=128, H=2, C=16, O=3, freq=(0.5, 1.0))
+    err, mse = run_case(cuda, cfg, B=2, N=70, Z=9, precision=precision)
+    assert err < TOL[precision], (invariant, precision, err)
+    assert mse < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("D,H,C,O,Z,N", [(128, 2, 16, 1, 64, 512), (64, 2, 16, 1, 16, 100), (128, 1, 32, 3, 18, 33),
+                                         (64, 1, 8, 2, 4, 32), (128, 2, 16, 1, 3, 40)])
+def test_forward_shapes(cuda, D, H, C, O, Z, N, precision):
+    cfg = make_cfg("rel_pos_periodic", D=D, H=H, C=C, O=O)
+    err, mse = run_case(cuda, cfg, B=3, N=N, Z=Z, precision=precision, seed=D + Z)
+    assert err < TOL[precision], err
+    assert mse < 1e-5
+
+
+def test_forward_broadcast_grid(cuda):
+    cfg = make_cfg("rel_pos_periodic")
+    err, _ = run_case(cuda, cfg, B=4, N=200, Z=16, precision="f32", broadcast_x=True)
+    assert err < TOL["f32"]
+
+
+def test_forward_no_window(cuda):
+    cfg = make_cfg("rel_pos", use_window=False, freq=(0.5, 0.5))
+    err, _ = run_case(cuda, cfg, B=2, N=64, Z=8, precision="f32")
+    assert err < TOL["f32"]
