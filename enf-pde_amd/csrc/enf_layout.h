@@ -87,7 +87,8 @@ struct EnfLayout {
   size_t aq1, av1, af, agb, am;         // KBxKB each; agb: 2H stages of KBxKB
   size_t atb, atf1, ato0, ato2, ato4;   // KBHxKBH, KBHxKBH, KBxKBH, KBxKB, OBxKB
   // ---- backward panels (A operand = W, in x out): dX = W dY
-  size_t gq1, gv1, gf, ggb, gm;         // KBxKB; ggb: KB x (2H*KB)  (out = D, in = 2HD)
+  size_t gq1, gv1, gf, ggb, gm;         // KBxKB; ggb: H panels of KB x 2KB (out = D, in = that head's [g b ..] 2D)
+  size_t gcq, gcv;                      // 1 x D/64: A[c][t] = 2 pi coeff[c][t]  (d inv = 2 pi coeff d t)
   size_t gtb, gtf1, gto0, gto2, gto4;   // KBHxKBH, KBHxKBH, KBHxKB, KBxKB, KBxOB
   // ---- plain fp32 (in,out) copies of folded matrices
   size_t p_af, p_agb, p_wb, p_wf1, p_tmp, p_o4;   // DxD, Dx2HD, HDxHD, HDxHD, HDxHD, Dx(32*OB)
@@ -120,6 +121,7 @@ inline EnfLayout enf_layout(const EnfDims& m) {
   L.gq1 = take(enf_panel_bytes(KB, KB, bf)); L.gv1 = take(enf_panel_bytes(KB, KB, bf));
   L.gf = take(enf_panel_bytes(KB, KB, bf)); L.ggb = take(enf_panel_bytes(KB, 2 * H * KB, bf));
   L.gm = take(enf_panel_bytes(KB, KB, bf));
+  L.gcq = take(enf_panel_bytes(1, D / 64, bf)); L.gcv = take(enf_panel_bytes(1, D / 64, bf));
   L.gtb = take(enf_panel_bytes(KBH, KBH, bf)); L.gtf1 = take(enf_panel_bytes(KBH, KBH, bf));
   L.gto0 = take(enf_panel_bytes(KBH, KB, bf)); L.gto2 = take(enf_panel_bytes(KB, KB, bf));
   L.gto4 = take(enf_panel_bytes(KB, OB, bf));

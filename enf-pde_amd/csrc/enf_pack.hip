@@ -62,7 +62,7 @@ __global__ void coef_frag_kernel(float* dst, const float* coeff, int I, int Dh /
 // fp32: byte (((m*KBin+blk)*4+r4)*64+lane)*16 + 4i <- A[32m + (lane&31)][32blk + 8 r4 + 4(lane>>5) + i]
 // (the k order is the one in which a 32x32 accumulator presents its rows as the next B operand)
 __global__ void pack_panel_kernel(void* dst, const float* W, int ldw, int R, int K, int trans, int bf16,
-                                  int Rvalid, int Kvalid) {
+                                  int Rvalid, int Kvalid, float scale) {
   const int KBin = K / 32;
   const size_t total = (size_t)R * K;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +82,7 @@ __global__ void pack_panel_kernel(void* dst, const float* W, int ldw, int R, int
     k = 32 * blk + 8 * r4 + 4 * (lane >> 5) + i;
   }
   float v = 0.f;
-  if (r < Rvalid && k < Kvalid) v = trans ? W[(size_t)r * ldw + k] : W[(size_t)k * ldw + r];
+  if (r < Rvalid && k < Kvalid) v = scale * (trans ? W[(size_t)r * ldw + k] : W[(size_t)k * ldw + r]);
   if (bf16) reinterpret_cast<__bf16*>(dst)[e] = (__bf16)v;
   else reinterpret_cast<float*>(dst)[e] = v;
 }
@@ -94,10 +94,10 @@ static inline int mm(hipStream_t st, float* C, int ldc, const float* A, int lda,
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 static inline int pack_panel(hipStream_t st, char* blob, size_t off, const float* W, int ldw, int R, int K, int trans,
-                             int bf16, int Rvalid = -1, int Kvalid = -1) {
+                             int bf16, int Rvalid = -1, int Kvalid = -1, float scale = 1.0f) {
   const size_t total = (size_t)R * K;
   hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (void*)(blob + off), W,
-                     ldw, R, K, trans, bf16, Rvalid < 0 ? R : Rvalid, Kvalid < 0 ? K : Kvalid);
+                     ldw, R, K, trans, bf16, Rvalid < 0 ? R : Rvalid, Kvalid < 0 ? K : Kvalid, scale);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
@@ -105,7 +105,7 @@ static inline int pack_panel(hipStream_t st, char* blob, size_t off, const float
 extern "C" int enf_debug_pack(void* dst, const float* W, int M, int K, int bf16, void* stream) {
   const size_t total = (size_t)M * K;
   hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, W, M,
-                     M, K, 0, bf16, M, K);
+                     M, K, 0, bf16, M, K, 1.0f);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
@@ -180,7 +180,11 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
   if ((rc = pack_panel(st, blob, L.gq1, T[ENF_W_RQ_W1], D, D, D, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gv1, T[ENF_W_RV_W1], D, D, D, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gf, F(L.p_af), D, D, D, 1, bf))) return rc;
-  if ((rc = pack_panel(st, blob, L.ggb, F(L.p_agb), 2 * HD, D, 2 * HD, 1, bf))) return rc;
+  for (int h = 0; h < H; ++h)   // one K-slice (that head's [g b g b ..] 2D columns) per head
+    if ((rc = pack_panel(st, blob, L.ggb + (size_t)h * enf_panel_bytes(m.KB, 2 * m.KB, bf), F(L.p_agb) + h * 2 * D, 2 * HD, D, 2 * D, 1, bf))) return rc;
+  // d inv[c] = sum_t 2 pi coeff[c][t] d t[t]  (RFF:92)
+  if ((rc = pack_panel(st, blob, L.gcq, T[ENF_W_RQ_COEF], D / 2, 32, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
+  if ((rc = pack_panel(st, blob, L.gcv, T[ENF_W_RV_COEF], D / 2, 32, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
   if ((rc = pack_panel(st, blob, L.gm, T[ENF_W_MX_W0], D, D, D, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gtb, F(L.p_wb), HD, HD, HD, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gtf1, F(L.p_wf1), HD, HD, HD, 1, bf))) return rc;

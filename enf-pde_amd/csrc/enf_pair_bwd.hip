@@ -1,7 +1,559 @@
-// placeholder until the backward pair kernel lands
+// enf_pair_bwd.hip -- K3: gradient of the pair chain w.r.t. the per-latent quantities
+// (u, v0, c, pose, window coefficient), i.e. the part of jax.grad(loss)(latents)
+// (pde_trainer.py:188,200) that touches every (query, latent) pair.
+//
+// "z-major": one wave owns ONE latent z of one signal and sweeps tiles of 32 queries
+// (columns = queries).  Everything per pair is recomputed in registers (nothing of size
+// B*N*Z is ever stored); reductions over queries -- the gradient of a per-latent quantity --
+// stay lane-local across the sweep and are folded across lanes once, at the end.
+// Softmax backward needs no reduction over z: with the forward's log-sum-exp and
+// delta[n,h] = d(ybar)[n,h,:] . ybar[n,h,:] (computed by the tail backward),
+//     att = exp(logit - lse),  d(logit) = att * (d(ybar).n~ - delta).
+// Per tile (H heads):  q-forward (logits) -> v-forward to n^ -> per head {gamma/beta, mixer
+// forward, mixer backward, FiLM backward, gamma/beta backward} -> LN/gelu/relu backward to the
+// value RFF -> q-branch recompute + backward -> invariant Jacobian.  608 MFMAs (32x32x16 bf16)
+// per tile at D=128, H=2 against 288 in the forward.
 #include <hip/hip_runtime.h>
 #include "enf_layout.h"
-extern "C" int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*,
-                                   const float*, const float*, const float*, float*, hipStream_t) {
+#include "enf_device.h"
+#include "enf_pair_common.h"
+
+struct PairBwdArgs {
+  const float* x; long long x_bstride;
+  const float* lt; const char* blob; EnfLayout L;
+  const float* lse; const float* dybar; const float* delta;
+  float* dlt;
+  int B, N, Z, dx, inv, use_window, nsplit;
+};
+
+template <int D, int H, bool BF16> struct PairBwdSmem {
+  static constexpr int TB = D / 64;
+  static constexpr int RING = 0;
+  static constexpr int CONSTS = RING + 2 * STAGE_MAX;
+  // bq1 bv1 bf bm (D each) | bgb (2HD) | acq acv ((D/64)*128 each)
+  static constexpr int N_CONST = 4 * D + 2 * H * D + 2 * (D / 64) * 128;
+  static constexpr int GC = CONSTS + 4 * N_CONST;                          // gcq | gcv panels
+  static constexpr int GC_BYTES = PanelCfg<TB, 1, BF16>::BYTES;
+  static constexpr int ZVEC = GC + 2 * GC_BYTES;                           // 4 waves x 2HD floats
+  static constexpr int TOTAL = ZVEC + 4 * 4 * 2 * H * D;
+};
+
+// gamma/beta panel that also returns 1+gamma (needed by d v0) -- same staging as gb_panel
+template <int D, bool BF16, int NEXT_BYTES>
+DEV void gb_panel_keep(f32x16 (&v)[D / 32], f32x16 (&opg)[D / 32], const Frags<BF16, D / 32>& F, Pipe& P, char* ring,
+                       unsigned panel, unsigned next, const float* bias, const float* v0vec, int tid, int lane, int half) {
+  using C = typename PairCfg<D, BF16>::GB;
+  constexpr int KB = D / 32, MBS = C::MBS;
+#pragma unroll
+  for (int sp = 0; sp < C::SPP; ++sp) {
+    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.regs, P.rs, panel + (sp + 1) * C::STAGE, tid);
+    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.regs, P.rs, next, tid);
+    f32x16 t[MBS];
+#pragma unroll
+    for (int j = 0; j < MBS; ++j) load_rowvec(t[j], bias, sp * MBS + j, half);
+    gemm_stage<BF16, KB, MBS>(t, F, ring + P.cur * STAGE_MAX, lane);
+#pragma unroll
+    for (int j = 0; j < MBS / 2; ++j) {
+      const int m = sp * (MBS / 2) + j;
+      f32x16 v0;
+      load_rowvec(v0, v0vec, m, half);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { opg[m][r] = 1.0f + t[2 * j][r]; v[m][r] = fmaf(v0[r], opg[m][r], t[2 * j + 1][r]); }
+    }
+    if (sp + 1 < C::SPP) stage_commit<C::STAGE>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
+    else if (next != NO_STAGE) stage_commit<NEXT_BYTES>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
+    __syncthreads();
+    P.cur ^= 1;
+  }
+}
+
+// d t = d E_sin * E_cos - d E_cos * E_sin   (the 2 pi is folded into the gc panel)
+template <int D> DEV void rff_embed_bwd(f32x16 (&dT)[D / 64], const f32x16 (&dE)[D / 32], const f32x16 (&E)[D / 32]) {
+  constexpr int TB = D / 64;
+#pragma unroll
+  for (int m = 0; m < TB; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dT[m][r] = dE[m][r] * E[TB + m][r] - dE[TB + m][r] * E[m][r];
+}
+
+// Jacobian of (invariant, window) w.r.t. the latent pose row and the window coefficient.
+// dinv: gradient of the I invariant components; dwin: gradient of the additive window term.
+template <bool FAST>
+DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& pz, float wcoef, int use_window,
+                            const float (&inv)[4], float win, float (&dinv)[4], float dwin, float (&dpose)[4],
+                            float& dwc) {
+  const float PI = 3.14159265358979323846f;
+  switch (inv_id) {
+    case ENF_INV_REL_POS_PERIODIC: {
+      if (use_window) {                                   // win = wc (c0^2 + c1^2)
+        dwc += dwin * (inv[0] * inv[0] + inv[1] * inv[1]);
+        dinv[0] += dwin * 2.f * wcoef * inv[0];
+        dinv[1] += dwin * 2.f * wcoef * inv[1];
+      }
+      dpose[0] += PI * (-inv[2] * dinv[0] + inv[0] * dinv[2]);   // d/dD0 [cos pi D0, sin pi D0], D = p - x
+      dpose[1] += PI * (-inv[3] * dinv[1] + inv[1] * dinv[3]);
+    } break;
+    case ENF_INV_LATITUDE_PERIODIC:
+    case ENF_INV_POLAR_PERIODIC: {
+      const float dphi = (q.x0 - pz[0]) * 0.15915494309189535f;
+      const float cd = cos_rev<FAST>(dphi), sd = sin_rev<FAST>(dphi);
+      const float dot = q.sx * pz[2] * cd + q.cx * pz[3];
+      float ddot = 0.f, dcd = 0.f, dsd = 0.f;
+      if (inv_id == ENF_INV_LATITUDE_PERIODIC) { dpose[1] += dinv[1]; dcd += dinv[2]; dsd += dinv[3]; }
+      else ddot += dinv[0];
+      if (use_window) {                                   // win = exp(-ang^2 wc), ang = acos(clip(dot))
+        const float dc = fminf(fmaxf(dot, -1.f + 1e-6f), 1.f - 1e-6f);
+        const float ang = acosf(dc);
+        dwc += dwin * (-ang * ang * win);
+        if (dot > -1.f + 1e-6f && dot < 1.f - 1e-6f)
+          ddot += dwin * (2.f * ang * wcoef * win) * rsqrtf(1.f - dc * dc);
+      }
+      dcd += ddot * q.sx * pz[2];
+      dpose[2] += ddot * q.sx * cd;                        // d/d sin(theta_p)
+      dpose[3] += ddot * q.cx;                             // d/d cos(theta_p)
+      dpose[0] += dcd * sd - dsd * cd;                     // d cd/d phi_p = sd, d sd/d phi_p = -cd
+    } break;
+    case ENF_INV_PONITA: {
+      const float r0 = q.x0 - pz[0], r1 = q.x1 - pz[1];
+      float dr0 = dinv[0] * pz[2] - dinv[1] * pz[3];
+      float dr1 = dinv[0] * pz[3] + dinv[1] * pz[2];
+      dpose[2] += dinv[0] * r0 + dinv[1] * r1;
+      dpose[3] += dinv[0] * r1 - dinv[1] * r0;
+      if (use_window) {                                   // win = -wc |r|^2
+        dwc += dwin * (-(r0 * r0 + r1 * r1));
+        dr0 += dwin * (-2.f * wcoef * r0);
+        dr1 += dwin * (-2.f * wcoef * r1);
+      }
+      dpose[0] -= dr0; dpose[1] -= dr1;
+    } break;
+    default: {
+      const float r0 = q.x0 - pz[0], r1 = dx > 1 ? q.x1 - pz[1] : 0.f, r2 = dx > 2 ? q.x2 - pz[2] : 0.f;
+      const float d2 = r0 * r0 + r1 * r1 + r2 * r2;
+      float dr0 = 0.f, dr1 = 0.f, dr2 = 0.f;
+      if (inv_id == ENF_INV_REL_POS) { dr0 = dinv[0]; dr1 = dinv[1]; dr2 = dinv[2]; }
+      else if (inv_id == ENF_INV_NORM_REL_POS) {
+        const float s = d2 > 0.f ? dinv[0] * rsqrtf(d2) : 0.f;
+        dr0 = s * r0; dr1 = s * r1; dr2 = s * r2;
+      }
+      if (use_window) {
+        dwc += dwin * (-d2);
+        dr0 += dwin * (-2.f * wcoef * r0); dr1 += dwin * (-2.f * wcoef * r1); dr2 += dwin * (-2.f * wcoef * r2);
+      }
+      dpose[0] -= dr0;
+      if (dx > 1) dpose[1] -= dr1;
+      if (dx > 2) dpose[2] -= dr2;
+    } break;
+  }
+}
+
+template <int D, int H, bool BF16>
+__global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
+  using Cfg = PairCfg<D, BF16>;
+  using SM = PairBwdSmem<D, H, BF16>;
+  constexpr int KB = Cfg::KB, TB = D / 64;
+  constexpr int ST_DD = Cfg::DD::STAGE, ST_GB = Cfg::GB::STAGE, PANEL_GB = Cfg::GB::BYTES;
+  using GG = PanelCfg<2 * KB, KB, BF16>;              // one head's d n^ += AGB_h [dgamma; dbeta]
+  constexpr int ST_GG = GG::STAGE, PANEL_GG = GG::BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem + SM::RING;
+  float* cst = reinterpret_cast<float*>(smem + SM::CONSTS);
+  float* c_bq1 = cst, *c_bv1 = cst + D, *c_bf = cst + 2 * D, *c_bm = cst + 3 * D, *c_bgb = cst + 4 * D;
+  float* c_acq = c_bgb + 2 * H * D, *c_acv = c_acq + (D / 64) * 128;
+  char* gcq = smem + SM::GC, *gcv = gcq + SM::GC_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  float* zv = reinterpret_cast<float*>(smem + SM::ZVEC) + wave * 2 * H * D;
+  const char* blob = A.blob;
+  auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
+
+  // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
+  const int bz = blockIdx.x * 4 + wave;
+  const bool active = bz < A.B * A.Z;
+  const int bzc = active ? bz : A.B * A.Z - 1;
+  const int b = bzc / A.Z;
+  const int split = blockIdx.y;
+
+  for (int i = tid; i < D; i += 256) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
+  for (int i = tid; i < 2 * H * D; i += 256) c_bgb[i] = G(A.L.bgb)[i];
+  for (int i = tid; i < (D / 64) * 128; i += 256) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
+  for (int i = tid; i < SM::GC_BYTES / 4; i += 256) {
+    reinterpret_cast<float*>(gcq)[i] = G(A.L.gcq)[i];
+    reinterpret_cast<float*>(gcv)[i] = G(A.L.gcv)[i];
+  }
+  const int ltstride = enf_lt_stride(H, D);
+  const float* ltrow = A.lt + (size_t)bzc * ltstride;
+#pragma unroll
+  for (int i = lane * 4; i < 2 * H * D; i += 256)
+    *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+  const f32x4 pz = *reinterpret_cast<const f32x4*>(ltrow + enf_lt_off_pose(H, D));
+  const float wcoef = ltrow[enf_lt_off_wcoef(H, D)];
+  float cz[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) cz[h] = ltrow[enf_lt_off_c(H, D) + h];
+
+  const unsigned pQ1 = (unsigned)A.L.aq1, pV1 = (unsigned)A.L.av1, pF = (unsigned)A.L.af, pGB = (unsigned)A.L.agb,
+                 pM = (unsigned)A.L.am, gQ1 = (unsigned)A.L.gq1, gV1 = (unsigned)A.L.gv1, gF = (unsigned)A.L.gf,
+                 gGB = (unsigned)A.L.ggb, gM = (unsigned)A.L.gm;
+
+  Pipe P;
+  P.cur = 0;
+  P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
+  stage_issue<ST_DD>(P.regs, P.rs, pQ1, tid);
+  stage_commit<ST_DD>(P.regs, ring, tid);
+  __syncthreads();
+
+  // per-lane partial sums over this wave's queries
+  f32x16 dU[H][KB], dV0[H][KB];
+  float dC[H], dpose[4] = {0.f, 0.f, 0.f, 0.f}, dwc = 0.f;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    dC[h] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dU[h][k][r] = 0.f; dV0[h][k][r] = 0.f; }
+  }
+
+  const int ntiles = (A.N + 31) / 32;
+  const int my_tiles = (ntiles - split + A.nsplit - 1) / A.nsplit;     // tiles split, split+nsplit, ..
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int n0 = (split + ti * A.nsplit) * 32;
+    const bool nvalid = n0 + col < A.N;
+    const int n = min(n0 + col, A.N - 1);
+    const size_t qrow = (size_t)b * A.N + n;
+    QueryPt q;
+    {
+      const float* xp = A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx;
+      q.x0 = xp[0]; q.x1 = A.dx > 1 ? xp[1] : 0.f; q.x2 = A.dx > 2 ? xp[2] : 0.f;
+      q.sx = 0.f; q.cx = 0.f;
+      if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) { q.sx = sinf(q.x1); q.cx = cosf(q.x1); }
+    }
+    float inv[4], win;
+    pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win);
+
+    // ---------------- q-forward: logits -> attention probabilities
+    float att[H], dlogit[H];
+    Frags<BF16, KB> F;
+    {
+      f32x16 E[KB];
+      rff_embed<D, BF16>(E, inv, c_acq, lane, half);
+      make_frags<BF16, KB>(F, E);
+      f32x16 acc[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) load_rowvec(acc[k], c_bq1, k, half);
+      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, pQ1, pV1, true, tid, lane);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          f32x16 u;
+          load_rowvec(u, zv + h * D, k, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s = fmaf(fmaxf(acc[k][r], 0.f), u[r], s);
+        }
+        const float lg = xhalf_sum(s) + cz[h] + win;
+        att[h] = __expf(lg - A.lse[qrow * H + h]);
+      }
+    }
+    // ---------------- v-forward to the normalised f
+    f32x16 Ev[KB];                       // value-branch RFF features (needed again by d t)
+    rff_embed<D, BF16>(Ev, inv, c_acv, lane, half);
+    unsigned long long relu_mask = 0ull; // bit (16k + r): a2[k][r] > 0
+    f32x16 a3[KB], nh[KB];
+    float mu1, r1;
+    {
+      make_frags<BF16, KB>(F, Ev);
+      f32x16 acc[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) load_rowvec(acc[k], c_bv1, k, half);
+      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, pV1, pF, true, tid, lane);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc[k][r] > 0.f) relu_mask |= 1ull << (16 * k + r);
+          acc[k][r] = fmaxf(acc[k][r], 0.f);
+        }
+      make_frags<BF16, KB>(F, acc);
+#pragma unroll
+      for (int k = 0; k < KB; ++k) load_rowvec(a3[k], c_bf, k, half);
+      panel_gemm<KB, KB, BF16, ST_GB>(a3, F, P, ring, pF, pGB, true, tid, lane);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nh[k][r] = gelu_f(a3[k][r]);
+      ln_stats<KB>(nh, mu1, r1);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nh[k][r] = (nh[k][r] - mu1) * r1;
+      make_frags<BF16, KB>(F, nh);
+    }
+    f32x16 dnh[KB];                      // d n^ accumulated over heads
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dnh[k][r] = 0.f;
+
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      f32x16 v[KB], opg[KB];
+      gb_panel_keep<D, BF16, ST_DD>(v, opg, F, P, ring, pGB + h * PANEL_GB, pM, c_bgb + 2 * h * D, zv + H * D + h * D, tid,
+                                    lane, half);
+      f32x16 a5[KB];
+      {
+        Frags<BF16, KB> FV;
+        make_frags<BF16, KB>(FV, v);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) load_rowvec(a5[k], c_bm, k, half);
+        panel_gemm<KB, KB, BF16, ST_DD>(a5, FV, P, ring, pM, gM, true, tid, lane);
+      }
+      // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
+      float mu2, r2;
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[k][r] = gelu_f(a5[k][r]);
+      ln_stats<KB>(v, mu2, r2);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[k][r] = (v[k][r] - mu2) * r2;
+      // d n~ = att * d ybar ;  d att = d ybar . n~ ;  softmax backward with the forward's lse / delta
+      f32x16 dy[KB];
+      {
+        const float* dyrow = A.dybar + qrow * (H * D) + h * D;
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(dyrow + 32 * k + 8 * g + 4 * half);
+            dy[k][4 * g] = t[0]; dy[k][4 * g + 1] = t[1]; dy[k][4 * g + 2] = t[2]; dy[k][4 * g + 3] = t[3];
+          }
+      }
+      float s0 = 0.f;
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0 = fmaf(dy[k][r], v[k][r], s0);
+      const float datt = xhalf_sum(s0);
+      dlogit[h] = nvalid ? att[h] * (datt - A.delta[qrow * H + h]) : 0.f;
+      const float ah = nvalid ? att[h] : 0.f;
+      // LayerNorm backward (d n~ = ah * dy), then gelu backward
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dy[k][r] *= ah; s1 += dy[k][r]; s2 = fmaf(dy[k][r], v[k][r], s2); }
+      const float m1 = xhalf_sum(s1) * (1.0f / D), m2 = xhalf_sum(s2) * (1.0f / D);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dy[k][r] = r2 * (dy[k][r] - m1 - v[k][r] * m2) * gelu_grad_f(a5[k][r]);   // d a5
+      // d v = AM d a5
+      {
+        Frags<BF16, KB> FA;
+        make_frags<BF16, KB>(FA, dy);
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[k][r] = 0.f;
+        panel_gemm<KB, KB, BF16, ST_GG>(v, FA, P, ring, gM, gGB + h * PANEL_GG, true, tid, lane);               // v <- d v
+      }
+      // FiLM backward: d v0 += d v (1+gamma); d gamma = d v * v0; d beta = d v
+      Frags<BF16, 2 * KB> FG;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        f32x16 v0;
+        load_rowvec(v0, zv + H * D + h * D, k, half);
+        f32x16 dgam;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dV0[h][k][r] = fmaf(v[k][r], opg[k][r], dV0[h][k][r]);
+          dgam[r] = v[k][r] * v0[r];
+        }
+        if constexpr (BF16) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              FG.f[2 * (2 * k) + s][j] = (__bf16)dgam[8 * s + j];
+              FG.f[2 * (2 * k + 1) + s][j] = (__bf16)v[k][8 * s + j];
+            }
+        } else {
+          FG.f[2 * k] = dgam;
+          FG.f[2 * k + 1] = v[k];
+        }
+      }
+      if (h + 1 < H) panel_gemm<2 * KB, KB, BF16, ST_GB>(dnh, FG, P, ring, gGB + h * PANEL_GG, pGB + (h + 1) * PANEL_GB, true, tid, lane);
+      else panel_gemm<2 * KB, KB, BF16, ST_DD>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, tid, lane);
+    }
+
+    // ---------------- LN / gelu backward -> d a3 -> AF -> relu -> W1v -> d E_v -> d t_v -> d inv
+    float dinv[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1 += dnh[k][r]; s2 = fmaf(dnh[k][r], nh[k][r], s2); }
+      const float m1 = xhalf_sum(s1) * (1.0f / D), m2 = xhalf_sum(s2) * (1.0f / D);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dnh[k][r] = r1 * (dnh[k][r] - m1 - nh[k][r] * m2) * gelu_grad_f(a3[k][r]);   // d a3
+      make_frags<BF16, KB>(F, dnh);
+      f32x16 acc[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, gF, gV1, true, tid, lane);                                 // d g1
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = ((relu_mask >> (16 * k + r)) & 1ull) ? acc[k][r] : 0.f;          // d a2
+      make_frags<BF16, KB>(F, acc);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, gV1, pQ1, true, tid, lane);                                // d E_v
+      f32x16 dT[TB];
+      rff_embed_bwd<D>(dT, acc, Ev);
+      Frags<BF16, TB> FT;
+      make_frags<BF16, TB>(FT, dT);
+      f32x16 di[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) di[0][r] = 0.f;
+      gemm_stage<BF16, TB, 1>(di, FT, gcv, lane);
+      if (half == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
+    }
+    // ---------------- q-branch: recompute h1, then d u, d c, d h1 -> W1q -> d E_q -> d t_q -> d inv
+    {
+      f32x16 E[KB];
+      rff_embed<D, BF16>(E, inv, c_acq, lane, half);
+      make_frags<BF16, KB>(F, E);
+      f32x16 acc[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) load_rowvec(acc[k], c_bq1, k, half);
+      const bool more = ti + 1 < my_tiles;
+      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, pQ1, gQ1, true, tid, lane);                                // a1
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          f32x16 u;
+          load_rowvec(u, zv + h * D, k, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float h1 = fmaxf(acc[k][r], 0.f);
+            dU[h][k][r] = fmaf(dlogit[h], h1, dU[h][k][r]);
+            dh[r] = fmaf(dlogit[h], u[r], dh[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = acc[k][r] > 0.f ? dh[r] : 0.f;                                   // d a1
+      }
+      Frags<BF16, KB> FA;
+      make_frags<BF16, KB>(FA, acc);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+      panel_gemm<KB, KB, BF16, ST_DD>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, tid, lane);             // d E_q
+      f32x16 dT[TB];
+      rff_embed_bwd<D>(dT, acc, E);
+      Frags<BF16, TB> FT;
+      make_frags<BF16, TB>(FT, dT);
+      f32x16 di[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) di[0][r] = 0.f;
+      gemm_stage<BF16, TB, 1>(di, FT, gcq, lane);
+      if (half == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
+    }
+    // ---------------- per-latent scalars (each column is counted once: lane half 0)
+    if (half == 0) {
+      float dwin = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) { dC[h] += dlogit[h]; dwin += dlogit[h]; }
+      pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc);
+    }
+  }
+
+  // ---- fold the 32 columns and add this wave's share into the latent-table gradient
+  if (!active) return;   // no barrier follows
+  float* drow = A.dlt + (size_t)bz * ltstride;
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = dU[h][k][r], c = dV0[h][k][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (col == 0) {
+          const int f = 32 * k + RHO(r, 0) + 4 * half;
+          atomicAdd(drow + enf_lt_off_u(H, D) + h * D + f, a);
+          atomicAdd(drow + enf_lt_off_v0(H, D) + h * D + f, c);
+        }
+      }
+  float sc[H + 5];
+#pragma unroll
+  for (int h = 0; h < H; ++h) sc[h] = dC[h];
+  sc[H] = dpose[0]; sc[H + 1] = dpose[1]; sc[H + 2] = dpose[2]; sc[H + 3] = dpose[3]; sc[H + 4] = dwc;
+#pragma unroll
+  for (int i = 0; i < H + 5; ++i) {
+    float a = half == 0 ? sc[i] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    sc[i] = a;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) atomicAdd(drow + enf_lt_off_c(H, D) + h, sc[h]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(drow + enf_lt_off_pose(H, D) + i, sc[H + i]);
+    atomicAdd(drow + enf_lt_off_wcoef(H, D), sc[H + 4]);
+  }
+}
+
+template <int D, int H, bool BF16>
+static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
+  using SM = PairBwdSmem<D, H, BF16>;
+  auto kern = enf_pair_bwd_kernel<D, H, BF16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL) != hipSuccess)
+      return ENF_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((A.B * A.Z + 3) / 4, A.nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), SM::TOTAL, st, A);
+  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+}
+
+extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
+                                   const float* lt, const float* lse, const float* dybar, const float* delta, float* dlt,
+                                   hipStream_t st) {
+  PairBwdArgs A;
+  A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;
+  A.dlt = dlt; A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
+  // split the query tiles over grid.y until the chip (256 CUs) has ~2 workgroups per CU
+  const int wgs = (m.B * m.Z + 3) / 4, ntiles = (m.N + 31) / 32;
+  int ns = 1;
+  while (wgs * ns < 512 && ns * 2 <= ntiles) ns *= 2;
+  A.nsplit = ns;
+#define ENF_CASE(DD, HH)                                                                   \
+  if (m.D == DD && m.H == HH) return m.bf16 ? launch_pair_bwd<DD, HH, true>(A, st) : launch_pair_bwd<DD, HH, false>(A, st);
+  ENF_CASE(128, 2)
+  ENF_CASE(64, 2)
+  ENF_CASE(128, 1)
+  ENF_CASE(64, 1)
+#undef ENF_CASE
   return ENF_EUNSUPPORTED;
 }

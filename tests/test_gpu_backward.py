@@ -1,0 +1,75 @@
+"""Backward-to-latents parity: HIP d/d(p, a, sigma) through the C-ABI against fp64 autograd of the
+torch oracle (the reference obtains these from jax.grad, pde_trainer.py:188,200)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import enf_ref_np as R
+from oracle import enf_ref_torch as T
+from tests.helpers import make_cfg, make_inputs, build_nef
+
+pytestmark = pytest.mark.gpu
+
+# relative L2 error of each gradient tensor
+TOL = {"f32": 2e-4, "bf16": 6e-2}
+
+
+def ref_grads(prm, cfg, x, p, a, s, w):
+    tp = T.to_torch(prm, torch.float64)
+    tx = torch.tensor(x)
+    tpp, ta, ts = (torch.tensor(v, requires_grad=True) for v in (p, a, s))
+    out = T.nef_apply(tp, cfg, tx, tpp, ta, ts)
+    (out * torch.tensor(w)).sum().backward()
+    z = lambda t: np.zeros(t.shape) if t.grad is None else t.grad.numpy()
+    return out.detach().numpy(), z(tpp), z(ta), z(ts)
+
+
+def hip_grads(cuda, nef, prm, x, p, a, s, w):
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    tp, ta, ts = t(p, True), t(a, True), t(s, True)
+    out = nef.apply(params, t(x), tp, ta, ts)
+    (out * t(w)).sum().backward()
+    torch.cuda.synchronize()
+    g = lambda v: np.zeros(tuple(v.shape)) if v.grad is None else v.grad.cpu().numpy().astype(np.float64)
+    return out.detach().cpu().numpy(), g(tp), g(ta), g(ts)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def check(cuda, cfg, B, N, Z, precision, seed=0, check_sigma=True):
+    prm = R.init_params(seed, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, B, N, Z, seed + 1)
+    w = np.random.default_rng(seed + 2).standard_normal((B, N, cfg["num_out"]))
+    _, rp, ra, rs = ref_grads(prm, cfg, x, p, a, s, w)
+    nef = build_nef(cfg, precision)
+    _, gp, ga, gs = hip_grads(cuda, nef, prm, x, p, a, s, w)
+    errs = {"p": rel(gp, rp) if np.linalg.norm(rp) > 0 else np.abs(gp).max(), "a": rel(ga, ra)}
+    if check_sigma and cfg.get("use_gaussian_window", True):
+        errs["sigma"] = rel(gs, rs)
+    for k, e in errs.items():
+        assert np.isfinite(e) and e < TOL[precision], (cfg["invariant"], precision, k, e, errs)
+    return errs
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("invariant", ["rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos",
+                                       "rel_pos", "norm_rel_pos"])
+def test_backward_invariants(cuda, invariant, precision):
+    cfg = make_cfg(invariant, D=128, H=2, C=16, O=3, freq=(0.5, 1.0))
+    check(cuda, cfg, B=2, N=70, Z=9, precision=precision)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("D,H,C,O,Z,N", [(128, 2, 16, 1, 64, 512), (64, 2, 16, 1, 16, 100), (128, 1, 32, 3, 18, 33),
+                                         (64, 1, 8, 2, 4, 32), (128, 2, 16, 1, 3, 40)])
+def test_backward_shapes(cuda, D, H, C, O, Z, N, precision):
+    cfg = make_cfg("rel_pos_periodic", D=D, H=H, C=C, O=O)
+    check(cuda, cfg, B=3, N=N, Z=Z, precision=precision, seed=D + Z)
+
+
+def test_backward_no_window(cuda):
+    cfg = make_cfg("rel_pos", use_window=False, freq=(0.5, 0.5))
+    check(cuda, cfg, B=2, N=64, Z=8, precision="f32")
