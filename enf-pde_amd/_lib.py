@@ -14,7 +14,7 @@ INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic"
 
 EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
-           "enf_backward_latents"]
+           "enf_backward_latents", "enf_forward_stages"]
 
 
 class EnfDesc(ctypes.Structure):
@@ -53,6 +53,7 @@ def load():
     lib.enf_workspace_bytes.argtypes = [dp]
     lib.enf_pack_weights.argtypes = [dp, ctypes.POINTER(vp), vp, vp]
     lib.enf_forward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.enf_forward_stages.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, ctypes.c_uint, vp]
     lib.enf_backward_latents.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     for name in ("enf_debug_gemm", "enf_debug_pack"):
         getattr(lib, name).restype = ci

@@ -65,9 +65,9 @@ extern "C" size_t enf_workspace_bytes(const EnfDesc* d) {
   return enf_workspace(enf_dims(d)).total;
 }
 
-extern "C" int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
-                           const float* sigma, const void* packed, float* out, float* ybar, float* lse, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
+                                  const float* sigma, const void* packed, float* out, float* ybar, float* lse,
+                                  void* workspace, size_t workspace_bytes, unsigned stages, void* stream) {
   int rc = enf_check_desc(d);
   if (rc) return rc;
   if (!x || !p || !a || !packed || !out || !workspace) return ENF_EINVAL;
@@ -82,10 +82,17 @@ extern "C" int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, 
   const char* blob = (const char*)packed;
   float* yb = ybar ? ybar : F(W.ybar);
   float* ls = lse ? lse : F(W.lse);
-  if ((rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
-  if ((rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, st))) return rc;
-  if ((rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, nullptr, 0, st))) return rc;
+  if ((stages & ENF_STAGE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
+  if ((stages & ENF_STAGE_PAIR) && (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, st))) return rc;
+  if ((stages & ENF_STAGE_TAIL) && (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, nullptr, 0, st))) return rc;
   return ENF_OK;
+}
+
+extern "C" int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
+                           const float* sigma, const void* packed, float* out, float* ybar, float* lse, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  return enf_forward_stages(d, x, x_bstride, p, a, sigma, packed, out, ybar, lse, workspace, workspace_bytes,
+                            ENF_STAGE_PROLOGUE | ENF_STAGE_PAIR | ENF_STAGE_TAIL, stream);
 }
 
 extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,

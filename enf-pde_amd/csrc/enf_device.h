@@ -123,32 +123,32 @@ template <bool FAST> DEV float cos_rev(float t) {
 constexpr int STAGE_MAX = 32768;
 constexpr unsigned NO_STAGE = 0xFFFFFFFFu;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct StageRegs { u32x4 r[STAGE_MAX / (256 * 16)]; };
 
-// Stage sources are byte offsets into the packed blob, read with buffer loads: descriptor and
-// stage offset live in SGPRs, the only per-lane address is tid*16 (no 64-bit address VGPRs for
-// the compiler to hoist and spill; cdna_hip_programming.md T8/T20).
+// Stage sources are byte offsets into the packed blob.  A stage moves global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds): each wave-instruction carries 1 KB (lane-linear, which is exactly
+// the fragment order the panels are packed in), no VGPR is touched, descriptor and offsets are
+// scalar (cdna_hip_programming.md section 5, T8).  The DMA is issued BEFORE the MFMAs that hide its
+// latency and retired by stage_wait() + the stage barrier.
 DEV __amdgpu_buffer_rsrc_t make_blob_rsrc(const char* blob, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(blob), 0, bytes, 0x00020000);
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <int BYTES>
-DEV void stage_issue(StageRegs& S, __amdgpu_buffer_rsrc_t rs, unsigned src_off, int tid) {
+DEV void stage_issue(__amdgpu_buffer_rsrc_t rs, unsigned src_off, char* dst, int wave, int lane) {
   static_assert(BYTES % 4096 == 0 && BYTES <= STAGE_MAX, "stage size");
 #pragma unroll
-  for (int i = 0; i < BYTES / 4096; ++i)
-    S.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, src_off + i * 4096, 0);
+  for (int i = 0; i < BYTES / 4096; ++i) {
+    const int piece = (i * 4 + wave) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + piece), 16, lane * 16, src_off + piece, 0, 0);
+  }
 }
-template <int BYTES>
-DEV void stage_commit(const StageRegs& S, char* dst, int tid) {
-#pragma unroll
-  for (int i = 0; i < BYTES / 4096; ++i)
-    *reinterpret_cast<u32x4*>(dst + (size_t)(i * 256 + tid) * 16) = S.r[i];
-}
+DEV void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Panel = (MBOUT out-blocks) x (KBIN in-blocks) of A-operand fragments, streamed through a
 // 2-slot LDS ring (slot stride STAGE_MAX) in stages of MBS out-blocks.
-struct Pipe { StageRegs regs; __amdgpu_buffer_rsrc_t rs; int cur; };
+struct Pipe { __amdgpu_buffer_rsrc_t rs; int cur; int wave; };
 
 template <int KBIN, int MBOUT, bool BF16> struct PanelCfg {
   static constexpr int FRAG = BF16 ? 2048 : 4096;
@@ -162,21 +162,19 @@ template <int KBIN, int MBOUT, bool BF16> struct PanelCfg {
 
 // acc[MBOUT] += panel . F.  Precondition: the panel's first stage is resident in ring[cur] and
 // visible (a barrier has passed).  While stage s is multiplied, stage s+1 (or the first stage of
-// `next`, NEXT_BYTES long; NO_STAGE = nothing follows) is fetched global -> registers, committed
-// to the other ring slot after the MFMAs, and published by the one barrier per stage.
-// `panel` / `next` are blob byte offsets (wave-uniform).  `active` (wave-uniform) lets a wave
-// without work keep the staging / barrier cadence.
+// `next`, NEXT_BYTES long; NO_STAGE = nothing follows) streams into the other ring slot; one
+// wait + one barrier per stage publish it.  `panel` / `next` are blob byte offsets (wave-uniform).
+// `active` (wave-uniform) lets a wave without work keep the staging / barrier cadence.
 template <int KBIN, int MBOUT, bool BF16, int NEXT_BYTES>
 DEV void panel_gemm(f32x16 (&acc)[MBOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel,
                     unsigned next, bool active, int tid, int lane) {
   using C = PanelCfg<KBIN, MBOUT, BF16>;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.regs, P.rs, panel + (sp + 1) * C::STAGE, tid);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.regs, P.rs, next, tid);
+    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
     if (active) gemm_stage<BF16, KBIN, C::MBS>(&acc[sp * C::MBS], F, ring + P.cur * STAGE_MAX, lane);
-    if (sp + 1 < C::SPP) stage_commit<C::STAGE>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
-    else if (next != NO_STAGE) stage_commit<NEXT_BYTES>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
+    stage_wait();
     __syncthreads();
     P.cur ^= 1;
   }

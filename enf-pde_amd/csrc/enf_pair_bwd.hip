@@ -46,8 +46,8 @@ DEV void gb_panel_keep(f32x16 (&v)[D / 32], f32x16 (&opg)[D / 32], const Frags<B
   constexpr int KB = D / 32, MBS = C::MBS;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.regs, P.rs, panel + (sp + 1) * C::STAGE, tid);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.regs, P.rs, next, tid);
+    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
     f32x16 t[MBS];
 #pragma unroll
     for (int j = 0; j < MBS; ++j) load_rowvec(t[j], bias, sp * MBS + j, half);
@@ -60,8 +60,7 @@ DEV void gb_panel_keep(f32x16 (&v)[D / 32], f32x16 (&opg)[D / 32], const Frags<B
 #pragma unroll
       for (int r = 0; r < 16; ++r) { opg[m][r] = 1.0f + t[2 * j][r]; v[m][r] = fmaf(v0[r], opg[m][r], t[2 * j + 1][r]); }
     }
-    if (sp + 1 < C::SPP) stage_commit<C::STAGE>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
-    else if (next != NO_STAGE) stage_commit<NEXT_BYTES>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
+    stage_wait();
     __syncthreads();
     P.cur ^= 1;
   }
@@ -197,8 +196,9 @@ __global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
   Pipe P;
   P.cur = 0;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
-  stage_issue<ST_DD>(P.regs, P.rs, pQ1, tid);
-  stage_commit<ST_DD>(P.regs, ring, tid);
+  P.wave = __builtin_amdgcn_readfirstlane(wave);
+  stage_issue<ST_DD>(P.rs, pQ1, ring, P.wave, lane);
+  stage_wait();
   __syncthreads();
 
   // per-lane partial sums over this wave's queries

@@ -18,8 +18,8 @@ DEV void gb_panel(f32x16 (&v)[D / 32], const Frags<BF16, D / 32>& F, Pipe& P, ch
   constexpr int KB = D / 32, MBS = C::MBS;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.regs, P.rs, panel + (sp + 1) * C::STAGE, tid);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.regs, P.rs, next, tid);
+    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
     f32x16 t[MBS];
 #pragma unroll
     for (int j = 0; j < MBS; ++j) load_rowvec(t[j], bias, sp * MBS + j, half);
@@ -32,8 +32,7 @@ DEV void gb_panel(f32x16 (&v)[D / 32], const Frags<BF16, D / 32>& F, Pipe& P, ch
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[m][r] = fmaf(v0[r], 1.0f + t[2 * j][r], t[2 * j + 1][r]);
     }
-    if (sp + 1 < C::SPP) stage_commit<C::STAGE>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
-    else if (next != NO_STAGE) stage_commit<NEXT_BYTES>(P.regs, ring + (P.cur ^ 1) * STAGE_MAX, tid);
+    stage_wait();
     __syncthreads();
     P.cur ^= 1;
   }

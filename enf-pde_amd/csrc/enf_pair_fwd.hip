@@ -20,6 +20,9 @@
 #include "enf_device.h"
 #include "enf_pair_common.h"
 
+#ifndef USE_IDMFMA
+#define USE_IDMFMA 0
+#endif
 struct PairFwdArgs {
   const float* x; long long x_bstride;
   const float* lt; const char* blob; EnfLayout L;
@@ -76,8 +79,9 @@ __global__ __launch_bounds__(256, 1) void enf_pair_fwd_kernel(PairFwdArgs A) {
   Pipe P;
   P.cur = 0;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
-  stage_issue<ST_DD>(P.regs, P.rs, pQ1, tid);
-  stage_commit<ST_DD>(P.regs, ring, tid);
+  P.wave = __builtin_amdgcn_readfirstlane(wave);
+  stage_issue<ST_DD>(P.rs, pQ1, ring, P.wave, lane);
+  stage_wait();
   __syncthreads();
 
   float sm_m[H], sm_l[H], sm_c[H];
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void enf_pair_fwd_kernel(PairFwdArgs A) {
         const float w = pe * rstd;
         sm_l[h] += pe;
         sm_c[h] = fmaf(w, mu, sm_c[h]);
-        if constexpr (BF16) {
+        if constexpr (BF16 && USE_IDMFMA) {
           // Y += w*g through the matrix pipe (identity A operand): the accumulators stay in the
           // MFMA register file instead of round-tripping through the VALU
 #pragma unroll

@@ -137,8 +137,9 @@ __global__ __launch_bounds__(256, 1) void enf_tail_fwd_kernel(TailArgs A) {
   Pipe P;
   P.cur = 0;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
-  stage_issue<T::ST_TB>(P.regs, P.rs, (unsigned)A.L.atb, tid);
-  stage_commit<T::ST_TB>(P.regs, ring, tid);
+  P.wave = __builtin_amdgcn_readfirstlane(wave);
+  stage_issue<T::ST_TB>(P.rs, (unsigned)A.L.atb, ring, P.wave, lane);
+  stage_wait();
   __syncthreads();
   f32x16 o4[1];
   tail_forward<D, H, BF16, false, 4096>(o4, A.ybar + (size_t)qi * T::HD, nullptr, A.blob, A.L, cst, P, ring, NO_STAGE, tid, lane, half);
@@ -169,8 +170,9 @@ __global__ __launch_bounds__(256, 1) void enf_tail_bwd_kernel(TailArgs A) {
   Pipe P;
   P.cur = 0;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
-  stage_issue<T::ST_TB>(P.regs, P.rs, (unsigned)A.L.atb, tid);
-  stage_commit<T::ST_TB>(P.regs, ring, tid);
+  P.wave = __builtin_amdgcn_readfirstlane(wave);
+  stage_issue<T::ST_TB>(P.rs, (unsigned)A.L.atb, ring, P.wave, lane);
+  stage_wait();
   __syncthreads();
   const char* blob = A.blob;
   f32x16 o4[1];

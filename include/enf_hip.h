@@ -112,6 +112,17 @@ int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float
                 const float* sigma, const void* packed, float* out, float* ybar, float* lse,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement hook: the same call as enf_forward, restricted to a subset of its kernels so that ONE
+ * kernel can be bracketed by events on `stream` (bench.py's roofline leg, rocprofv3 cross-check).
+ * stages: bit 0 = latent prologue (K1), bit 1 = pair kernel (K2), bit 2 = tail.  The latent table
+ * lives in `workspace` between calls, so run bit 0 once before timing bit 1. */
+#define ENF_STAGE_PROLOGUE 1u
+#define ENF_STAGE_PAIR 2u
+#define ENF_STAGE_TAIL 4u
+int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
+                       const float* sigma, const void* packed, float* out, float* ybar, float* lse,
+                       void* workspace, size_t workspace_bytes, unsigned stages, void* stream);
+
 /* Replaces jax.grad(loss)(latents) for one inner step (pde_trainer.py:188,200): given
  * dL/dout it returns dL/dp (B,Z,dp), dL/da (B,Z,C), dL/dsigma (B,Z,1).  Buffers are
  * overwritten, not accumulated.  `ybar`/`lse` come from enf_forward on the same inputs. */

@@ -1,0 +1,96 @@
+"""Generates the golden fixtures in this directory from the oracle (fp64 numpy forward, fp64 torch
+autograd gradients, one inner-loop trace).  The reference itself cannot be executed here (JAX/Flax
+absent), so these vectors pin the ORACLE (regression) and give the HIP path a fixed target; they do
+not pin the oracle to the reference ("parity unpinned", oracle/enf_ref_np.py).
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import enf_ref_np as R          # noqa: E402
+from oracle import enf_ref_torch as T       # noqa: E402
+from tests.helpers import make_cfg, make_inputs   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (cfg kwargs, B, N, Z, param seed, store weights?)
+CASES = {
+    "tiny_rel_pos_periodic": (dict(invariant="rel_pos_periodic", D=64, H=1, C=8, O=2), 2, 7, 4, 11, True),
+    "tiny_ponita": (dict(invariant="ponita", D=64, H=2, C=8, O=1, freq=(0.05, 0.2)), 2, 9, 4, 12, False),
+    "tiny_polar_periodic": (dict(invariant="polar_periodic", D=64, H=2, C=4, O=1, freq=(0.5, 0.5)), 2, 11, 6, 13, False),
+    "tiny_latitude_periodic": (dict(invariant="latitude_periodic", D=64, H=2, C=8, O=3, freq=(0.05, 0.2)), 1, 13, 8, 14, False),
+    "cfg2_rel_pos_periodic": (dict(invariant="rel_pos_periodic", D=128, H=2, C=16, O=1), 2, 64, 64, 15, False),
+}
+
+
+def flatten(tree, prefix=""):
+    out = {}
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            out.update(flatten(v, prefix + k + "/"))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def make_case(name):
+    kw, B, N, Z, seed, store_w = CASES[name]
+    cfg = make_cfg(**kw)
+    prm = R.init_params(seed, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, B, N, Z, seed + 100)
+    w = np.random.default_rng(seed + 200).standard_normal((B, N, cfg["num_out"]))
+    out = R.nef_apply(prm, cfg, x, p, a, s)
+    tp = T.to_torch(prm, torch.float64)
+    tpp, ta, ts = (torch.tensor(v, requires_grad=True) for v in (p, a, s))
+    o2 = T.nef_apply(tp, cfg, torch.tensor(x), tpp, ta, ts)
+    (o2 * torch.tensor(w)).sum().backward()
+    assert np.abs(o2.detach().numpy() - out).max() < 1e-10
+    rec = dict(x=x, p=p, a=a, sigma=s, w=w, out=out, dp=tpp.grad.numpy(), da=ta.grad.numpy(), dsigma=ts.grad.numpy(),
+               param_seed=np.int64(seed), jitter=np.float64(0.1))
+    if store_w:
+        for k, v in flatten(prm["params"]).items():
+            rec["W/" + k] = v.astype(np.float32)
+        # outputs for the fp32-rounded weights actually stored
+        prm32 = R.init_params(seed, cfg, jitter=0.1)
+    return cfg, rec
+
+
+def make_inner_loop():
+    """3-step inner-loop trace (explicit masks) at BASELINE config 1's shape family, fp64."""
+    cfg = make_cfg(invariant="ponita", D=64, H=2, C=16, O=1, freq=(0.05, 0.01))
+    prm = R.init_params(21, cfg, jitter=0.05)
+    B, Z, S, Ns = 2, 4, 3, 48
+    g = 12
+    lin = np.linspace(-1, 1, g)
+    coords = np.stack(np.meshgrid(lin, lin), -1).reshape(-1, 2)
+    rng = np.random.default_rng(22)
+    img = np.cos(np.pi * coords @ rng.standard_normal((2, B))).T[..., None] + 0.1 * rng.standard_normal((B, g * g, 1))
+    masks = np.stack([rng.permutation(g * g)[:Ns] for _ in range(S + 1)], 1)
+    lat = R.init_latents(1, Z, 16, "ponita")
+    lrs = {"p_pos": np.array([1.0]), "p_ori": np.array([1.0]), "a": np.full(16, 5.0), "gaussian_window": np.array([0.0])}
+    t64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
+    loss, fitted = T.inner_loop(T.to_torch(prm, torch.float64), cfg, {k: t64(v) for k, v in lat.items()},
+                                {k: t64(v) for k, v in lrs.items()}, t64(coords), t64(img), torch.tensor(masks))
+    rec = dict(coords=coords, img=img, masks=masks, loss=np.float64(loss.item()), param_seed=np.int64(21), jitter=np.float64(0.05))
+    for k, v in lat.items():
+        rec["lat0/" + k] = v
+    for k, v in lrs.items():
+        rec["lr/" + k] = v
+    for k, v in fitted.items():
+        rec["fit/" + k] = v.detach().numpy()
+    return rec
+
+
+if __name__ == "__main__":
+    for name in CASES:
+        cfg, rec = make_case(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+        print(name, {k: v.shape for k, v in rec.items() if hasattr(v, "shape") and not k.startswith("W/")})
+    np.savez_compressed(os.path.join(HERE, "inner_loop_ponita.npz"), **make_inner_loop())
+    print("inner_loop_ponita written")

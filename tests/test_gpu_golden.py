@@ -1,0 +1,134 @@
+"""HIP path (through the C-ABI) against the committed golden vectors, the inner-loop trace, and
+size-independent properties at BASELINE.json's full config-2 size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import enf_ref_np as R
+from tests.helpers import make_cfg, make_inputs, build_nef
+from tests.golden.make_golden import CASES
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL_OUT = {"f32": 2e-5, "bf16": 3e-2}      # max|err| / max|ref|
+TOL_GRAD = {"f32": 2e-4, "bf16": 6e-2}     # relative L2
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_forward_backward(cuda, name, precision):
+    kw, B, N, Z, seed, _ = CASES[name]
+    cfg = make_cfg(**kw)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    prm = R.init_params(int(g["param_seed"]), cfg, jitter=float(g["jitter"]))
+    nef = build_nef(cfg, precision)
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v, rg=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=rg)
+    p, a, s = t(g["p"], True), t(g["a"], True), t(g["sigma"], True)
+    out = nef.apply(params, t(g["x"]), p, a, s)
+    (out * t(g["w"])).sum().backward()
+    torch.cuda.synchronize()
+    o = out.detach().cpu().numpy().astype(np.float64)
+    assert np.abs(o - g["out"]).max() / np.abs(g["out"]).max() < TOL_OUT[precision]
+    assert ((o - g["out"]) ** 2).mean() < 1e-5                   # BASELINE.json: field MSE <= 1e-5
+    for key, ten in (("dp", p), ("da", a), ("dsigma", s)):
+        assert _rel(ten.grad.cpu().numpy().astype(np.float64), g[key]) < TOL_GRAD[precision], (name, key)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_inner_loop_matches_golden_trace(cuda, precision):
+    """3 meta-SGD steps with explicit masks (pde_trainer.py:191-235) against the fp64 trace."""
+    from enf_pde_amd.fitting import inner_loop
+    g = np.load(os.path.join(GOLD, "inner_loop_ponita.npz"))
+    cfg = make_cfg(invariant="ponita", D=64, H=2, C=16, O=1, freq=(0.05, 0.01))
+    prm = R.init_params(int(g["param_seed"]), cfg, jitter=float(g["jitter"]))
+    nef = build_nef(cfg, precision)
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(np.asarray(v), dtype=torch.float32, device=cuda)
+    lat0 = {k[5:]: t(g[k]) for k in g.files if k.startswith("lat0/")}
+    lrs = {k[3:]: t(g[k]) for k in g.files if k.startswith("lr/")}
+    loss, fit = inner_loop(nef, params, lat0, lrs, t(g["coords"]), t(g["img"]), torch.tensor(g["masks"], device=cuda))
+    tol = 5e-4 if precision == "f32" else 5e-2
+    assert abs(loss.item() - float(g["loss"])) < tol * max(1.0, float(g["loss"]))
+    for k, v in fit.items():
+        ref = g["fit/" + k]
+        # compare the UPDATE (fitted - init), which is what the inner loop computes
+        init = np.repeat(g["lat0/" + k], ref.shape[0], 0)
+        if np.abs(ref - init).max() == 0:
+            assert np.abs(v.cpu().numpy() - ref).max() == 0, k     # gaussian_window frozen (TR:210-212)
+        else:
+            assert _rel(v.cpu().numpy() - init, ref - init) < tol * 20, k
+
+
+def test_full_size_properties(cuda):
+    """BASELINE config 2 at full size (B=2, N=64^2, Z=64): properties that need no oracle run."""
+    cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
+    prm = R.init_params(3, cfg, jitter=0.1)
+    nef = build_nef(cfg, "f32")
+    params = nef.load_params(prm, device=cuda)
+    lin = np.linspace(-1, 1, 64)
+    coords = np.stack(np.meshgrid(lin, lin), -1).reshape(-1, 2)
+    _, p, a, s = make_inputs(cfg, 2, 8, 64, 5)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    x = t(coords)[None].expand(2, -1, -1)                       # stride-0 batch
+    base = nef.apply(params, x, t(p), t(a), t(s))
+    scale = base.abs().max().item()
+    # (1) permutation of the latent set
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(0)).to(cuda)
+    o1 = nef.apply(params, x, t(p)[:, perm], t(a)[:, perm], t(s)[:, perm])
+    assert (o1 - base).abs().max().item() < 2e-5 * scale
+    # (2) joint translation, and period-2 shifts of individual coordinates
+    sh = torch.tensor([0.25, -0.5], device=cuda)
+    o2 = nef.apply(params, (x + sh).contiguous(), t(p) + sh, t(a), t(s))
+    assert (o2 - base).abs().max().item() < 5e-5 * scale
+    p3 = t(p).clone()
+    p3[:, ::3, 0] += 2.0
+    o3 = nef.apply(params, x, p3, t(a), t(s))
+    assert (o3 - base).abs().max().item() < 5e-5 * scale
+    # (3) query-chunked decode == one call (pde_trainer.py:397-402), materialised x == broadcast x
+    from enf_pde_amd.fitting import decode
+    o4 = decode(nef, params, t(coords), t(p), t(a), t(s), chunk=512)
+    assert torch.equal(o4, base)
+    o5 = nef.apply(params, x.contiguous(), t(p), t(a), t(s))
+    assert torch.equal(o5, base)
+    # (4) determinism
+    assert torch.equal(nef.apply(params, x, t(p), t(a), t(s)), base)
+    # (5) bf16 mode stays within the BASELINE field-MSE budget of the fp32-exact path
+    nb = build_nef(cfg, "bf16")
+    ob = nb.apply(nb.load_params(prm, device=cuda), x, t(p), t(a), t(s))
+    assert ((ob - base) ** 2).mean().item() < 1e-5
+
+
+def test_ragged_and_tiny_shapes(cuda):
+    """Empty-ish / ragged inputs: N not a multiple of 32, Z not a multiple of 4, Z=1, N=1, B=1."""
+    for (B, N, Z) in ((1, 1, 1), (2, 31, 5), (1, 33, 2), (3, 95, 7)):
+        cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=8, O=2)
+        prm = R.init_params(B + N + Z, cfg, jitter=0.1)
+        x, p, a, s = make_inputs(cfg, B, N, Z, 9)
+        ref = R.nef_apply(prm, cfg, x, p, a, s)
+        nef = build_nef(cfg, "f32")
+        t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+        out = nef.apply(nef.load_params(prm, device=cuda), t(x), t(p), t(a), t(s)).cpu().numpy()
+        assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), (B, N, Z)
+
+
+def test_loud_failure_modes(cuda):
+    from enf_pde_amd import _lib
+    cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=8, O=1)
+    nef = build_nef(cfg, "f32")
+    params = nef.load_params(R.init_params(0, cfg), device=cuda)
+    t = lambda *s: torch.zeros(*s, device=cuda)
+    with pytest.raises(AssertionError):
+        nef.apply(params, t(1, 8, 3), t(1, 4, 2), t(1, 4, 8), t(1, 4, 1) + 1)       # wrong coordinate width
+    with pytest.raises(AssertionError):
+        nef.apply(params, t(1, 8, 2), t(1, 4, 2), t(1, 4, 9), t(1, 4, 1) + 1)       # wrong latent_dim
+    with pytest.raises(AssertionError):
+        nef.apply(params, t(1, 8, 2), t(1, 4, 2), t(1, 4, 8), None)                 # window requested, no sigma
+    with pytest.raises(_lib.EnfError):
+        nef.apply(params, t(1, 8, 2).cpu(), t(1, 4, 2), t(1, 4, 8), t(1, 4, 1) + 1)  # host tensor

@@ -1,0 +1,186 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol of include/enf_hip.h
+(no compute without a GPU), descriptor validation / error mapping, and the host-side mirror of the
+reference interface (constructor keywords, parameter tree, latents, error behaviour)."""
+import ctypes
+import os
+import re
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import enf_ref_np as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from enf_pde_amd import _lib
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "enf_hip.h")).read()
+    declared = set(re.findall(r"\b(enf_[a-z_]+)\s*\(", hdr))
+    assert {"enf_forward", "enf_backward_latents", "enf_pack_weights", "enf_packed_weight_bytes", "enf_workspace_bytes",
+            "enf_strerror", "enf_check_desc", "enf_forward_stages"} <= declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.enf_abi_version() == 1
+
+
+def test_desc_struct_matches_header():
+    from enf_pde_amd import _lib
+    assert ctypes.sizeof(_lib.EnfDesc) == 16 * 4
+    hdr = open(os.path.join(ROOT, "include", "enf_hip.h")).read()
+    assert "ENF_NUM_TENSORS" in hdr and _lib.ENF_NUM_TENSORS == 46
+    # enum order of the invariants is the binding's id table
+    ids = re.findall(r"ENF_INV_([A-Z_]+) = (\d)", hdr)
+    for name, i in ids:
+        if name != "COUNT":
+            assert _lib.INVARIANT_IDS[name.lower()] == int(i)
+
+
+def test_check_desc_and_error_mapping(lib):
+    from enf_pde_amd import _lib
+    ok = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1)
+    assert lib.enf_check_desc(ctypes.byref(ok)) == 0
+    assert lib.enf_packed_weight_bytes(ctypes.byref(ok)) > 531585 * 2
+    assert lib.enf_workspace_bytes(ctypes.byref(ok)) > 0
+    bad_inv = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 9, 1, 1)
+    with pytest.raises(ValueError, match="Unknown invariant"):
+        _lib.check(lib.enf_check_desc(ctypes.byref(bad_inv)))
+    bad_dim = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 3, 0, 1, 1)     # rel_pos_periodic needs num_in == 2
+    with pytest.raises(AssertionError):
+        _lib.check(lib.enf_check_desc(ctypes.byref(bad_dim)))
+    unsupported = _lib.make_desc(2, 100, 64, 3, 32, 16, 1, 2, 0, 1, 1)
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.enf_check_desc(ctypes.byref(unsupported)))
+    empty = _lib.make_desc(0, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1)
+    with pytest.raises(_lib.EnfError):
+        _lib.check(lib.enf_check_desc(ctypes.byref(empty)))
+    assert lib.enf_packed_weight_bytes(ctypes.byref(unsupported)) == 0
+    assert lib.enf_invariant_dim(0, 2) == 4 and lib.enf_invariant_dim(2, 2) == 1 and lib.enf_invariant_dim(4, 3) == 3
+    assert lib.enf_invariant_pose_dim(3, 2) == 3
+    # NULL buffers are rejected before anything touches the (absent) GPU
+    assert lib.enf_forward(ctypes.byref(ok), None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
+
+
+def test_invariant_factory_mirrors_reference():
+    from enf_pde_amd.enf.steerable_attention.invariant import get_ca_invariant, get_sa_invariant
+    for name in ("rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos", "rel_pos", "norm_rel_pos"):
+        inv = get_ca_invariant(NS(invariant_type=name, num_in=2))
+        spec = R.invariant_spec(name, 2)
+        assert (inv.dim, inv.num_x_pos_dims, inv.num_z_pos_dims, inv.num_z_ori_dims) == \
+               (spec["dim"], spec["dx"], spec["z_pos"], spec["z_ori"]), name
+    assert get_ca_invariant(NS(invariant_type="rel_pos", num_in=3)).dim == 3
+    assert type(get_sa_invariant(NS(invariant_type="ponita", num_in=2))).__name__ == "PonitaPos2D"
+    with pytest.raises(ValueError, match="Unknown invariant type"):
+        get_ca_invariant(NS(invariant_type="bogus", num_in=2))
+    with pytest.raises(AssertionError):
+        get_ca_invariant(NS(invariant_type="rel_pos_periodic", num_in=3))
+    with pytest.raises(NotImplementedError):
+        get_ca_invariant(NS(invariant_type="ball", num_in=3))
+
+
+def _nef(**kw):
+    from enf_pde_amd.enf.models import EquivariantCrossAttentionNeF
+    from enf_pde_amd.enf.steerable_attention.invariant import get_ca_invariant
+    inv = get_ca_invariant(NS(invariant_type=kw.pop("invariant", "rel_pos_periodic"), num_in=2))
+    args = dict(num_hidden=128, num_heads=2, num_layers=0, num_out=1, latent_dim=16, cross_attn_invariant=inv,
+                self_attn_invariant=inv, embedding_type="rff", embedding_freq_multiplier=(0.05, 0.1),
+                condition_value_transform=True, use_gaussian_window=True)
+    args.update(kw)
+    return EquivariantCrossAttentionNeF(**args)
+
+
+def test_model_constructor_errors():
+    with pytest.raises(ValueError, match="Unknown embedding type"):
+        _nef(embedding_type="siren")
+    with pytest.raises(NotImplementedError):
+        _nef(embedding_type="polynomial")
+    with pytest.raises(NotImplementedError):
+        _nef(num_layers=2)
+    with pytest.raises(AssertionError):
+        _nef(num_hidden=63)
+
+
+def test_param_tree_matches_oracle_tree_and_count():
+    from enf_pde_amd.enf.models import TENSOR_PATHS
+    nef = _nef()
+    prm = nef.init(0, device="cpu")
+    ts = nef.param_tensors(prm)
+    assert sum(t.numel() for t in ts) == 531585
+    assert [tuple(t.shape) for t in ts] == nef._expected_shapes()
+    ref = R.init_params(0, dict(num_hidden=128, num_heads=2, latent_dim=16, num_out=1, invariant="rel_pos_periodic",
+                                embedding_freq_multiplier=(0.05, 0.1)))
+    for path in TENSOR_PATHS:           # same names, same shapes as the Flax tree restated by the oracle
+        node = ref["params"]
+        for k in path:
+            node = node[k]
+        t = prm["params"]
+        for k in path:
+            t = t[k]
+        assert tuple(node.shape) == tuple(t.shape), path
+    # initialiser statistics: RFF coefficients ~ N(0, std^2), LN scale 1, Dense bias 0
+    q = prm["params"]["cross_attention_blocks_0"]["attn"]["invariant_embedding_query"]
+    assert abs(q["encoding"]["coefficients"].std().item() - 0.05) < 0.01
+    assert abs(q["layers_0"]["linear"]["kernel"].std().item() - (2 / 128) ** 0.5) < 0.01
+    assert abs(q["linear_final"]["kernel"].abs().max().item() - (6 / 128) ** 0.5) < 0.01
+    assert torch.all(prm["params"]["latent_stem"]["bias"] == 0)
+    loaded = nef.load_params(ref, device="cpu")
+    assert torch.allclose(loaded["params"]["out_proj"]["layers_4"]["kernel"].double(),
+                          torch.tensor(ref["params"]["out_proj"]["layers_4"]["kernel"]), atol=1e-7)
+
+
+def test_apply_without_gpu_fails_loudly():
+    from enf_pde_amd import _lib
+    nef = _nef()
+    prm = nef.init(0, device="cpu")
+    x, p, a, s = torch.zeros(1, 8, 2), torch.zeros(1, 4, 2), torch.ones(1, 4, 16), torch.ones(1, 4, 1)
+    with pytest.raises(_lib.EnfError, match="no CPU path"):
+        nef.apply(prm, x, p, a, s)
+
+
+def test_latent_containers_match_reference_init():
+    from enf_pde_amd.enf.latents.autodecoder_meta import PositionOrientationFeatureAutodecoderMeta
+    from enf_pde_amd.enf.latents.autodecoder import PositionOrientationFeatureAutodecoder
+    ad = PositionOrientationFeatureAutodecoderMeta(num_signals=1, num_latents=64, latent_dim=16, num_pos_dims=2,
+                                                   num_ori_dims=0, gaussian_window_size=-1, coordinate_system="cartesian")
+    P = ad.init(device="cpu")
+    ref = R.init_latents(1, 64, 16, "rel_pos_periodic")
+    assert set(P["params"]) == {"p_pos", "a", "gaussian_window"}
+    for k in ref:
+        assert np.allclose(P["params"][k].numpy(), ref[k], atol=1e-6), k
+    p, a, w = ad.apply(P)
+    assert p.shape == (1, 64, 2) and a.shape == (1, 64, 16) and w.shape == (1, 64, 1)
+    pol = PositionOrientationFeatureAutodecoder(3, 128, 32, 2, 0, coordinate_system="polar").init(device="cpu")
+    refp = R.init_latents(3, 128, 32, "latitude_periodic", coordinate_system="polar")
+    assert np.allclose(pol["params"]["p_pos"].numpy(), refp["p_pos"], atol=1e-6)
+    assert np.allclose(pol["params"]["gaussian_window"].numpy(), refp["gaussian_window"], atol=1e-6)
+    pon = PositionOrientationFeatureAutodecoderMeta(1, 16, 8, 2, 1, gaussian_window_size=-1).init(device="cpu")
+    assert np.allclose(pon["params"]["p_ori"].numpy(), R.init_latents(1, 16, 8, "ponita")["p_ori"], atol=1e-6)
+    pp, _, _ = PositionOrientationFeatureAutodecoderMeta(1, 16, 8, 2, 1, gaussian_window_size=-1).apply(pon)
+    assert pp.shape == (1, 16, 3)
+    nowin = PositionOrientationFeatureAutodecoderMeta(1, 16, 8, 2, 0, gaussian_window_size=None)
+    assert nowin.apply(nowin.init(device="cpu"))[2] is None                      # ADM:21-24
+
+
+def test_get_model_pde_and_fit_helpers():
+    from enf_pde_amd.fitting import get_model_pde, make_masks, default_meta_sgd_lrs, shard_range
+    cfg = NS(nef=NS(num_in=2, num_out=1, num_layers=0, num_hidden=128, num_heads=2, condition_value_transform=True,
+                    latent_dim=16, num_latents=64, use_gaussian_window=True, embedding_type="rff",
+                    embedding_freq_multiplier_invariant=0.05, embedding_freq_multiplier_value=0.1,
+                    invariant_type="rel_pos_periodic"))
+    nef, ode = get_model_pde(cfg)
+    assert ode is None and nef.cross_attn_invariant.num_z_pos_dims == 2 and nef.cross_attn_invariant.num_z_ori_dims == 0
+    m = make_masks(100, 30, 3, generator=torch.Generator().manual_seed(0), device="cpu")
+    assert m.shape == (30, 4) and all(len(set(m[:, j].tolist())) == 30 for j in range(4))
+    lrs = default_meta_sgd_lrs(16, device="cpu", with_ori=True)
+    assert lrs["a"].shape == (16,) and lrs["p_pos"].shape == (1,) and set(lrs) == {"p_pos", "a", "gaussian_window", "p_ori"}
+    for n, w in ((16, 8), (17, 4), (3, 8), (64, 1)):
+        parts = [shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
