@@ -1,94 +1,89 @@
 // enf_device.h -- device building blocks shared by the pair / tail kernels (gfx950 only).
 //
-// Activation layout ("acc layout"): a 32-feature x 32-column tile lives in one f32x16 per
-// lane, exactly as v_mfma_f32_32x32x* writes its C/D operand:
-//     column = lane & 31,  feature row = RHO(reg, lane >> 5) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-// Columns are pairs (query n, latent z) or queries; features are network channels.  Every layer
-// is computed TRANSPOSED, Y^T = W^T X^T, so the previous layer's accumulator is directly the
-// next MFMA's B operand (cdna_hip_programming.md section 3, "An accumulator tile as the next
-// MFMA's operand"): no LDS round trip and no cross-lane traffic between layers.  The weight
-// panels are pre-packed in A-operand fragment order with the matching k permutation (enf_pack.hip).
+// Activation layout ("acc layout"): a TILE = 16 features x 16 columns lives in one f32x4 per
+// lane, exactly as v_mfma_f32_16x16x* writes its C/D operand:
+//     column = lane & 15,   feature row = 4*(lane >> 4) + reg          (quad q = lane >> 4)
+// A D-wide activation is NT = D/16 tiles (f32x4 X[NT]); two consecutive tiles form a 32-feature
+// BLOCK, the K extent of one bf16 MFMA.  Columns are pairs (query n, latent z) or queries.
+// Every layer is computed TRANSPOSED, Y^T = W^T X^T, so the previous layer's accumulator is
+// directly the next MFMA's B operand (cdna_hip_programming.md section 3, "An accumulator tile as
+// the next MFMA's operand"): no LDS round trip and no cross-lane traffic between layers.  The
+// weight panels are pre-packed in A-operand fragment order with the matching k permutation
+// (enf_pack.hip).  One wave owns 16 columns; a workgroup is 8 waves = 2 per SIMD, which keeps
+// every wave under 256 registers, doubles the VALU issue rate a lone wave gets and lets one
+// wave's VALU epilogue run under the other's MFMAs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
 #define DEV __device__ __forceinline__
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-DEV constexpr int RHO(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+constexpr int NWAVES = 8;            // waves per workgroup
+constexpr int NTHREADS = 64 * NWAVES;
 
 // ------------------------------------------------------------------ B-operand fragments
+// bf16: one bf16x8 per 32-feature block; element j (k = 8q + j) is feature 16(j>>2) + 4q + (j&3),
+//       i.e. tile (j>>2) register (j&3) of this lane.
+// fp32: v_mfma_f32_16x16x4_f32 #(tile, i) takes X[tile][i] as is (k = q <-> feature 16 tile + 4q + i).
 template <bool BF16, int KB>
 struct Frags {
-  using T = typename std::conditional<BF16, bf16x8, f32x16>::type;
-  T f[BF16 ? 2 * KB : KB];
+  using T = typename std::conditional<BF16, bf16x8, f32x4>::type;
+  T f[BF16 ? KB : 2 * KB];
 };
 
-// X: KB blocks in acc layout -> fragments of the next layer's B operand.
-// bf16: element j of k-step s of block blk is X[blk][8s+j]  (feature 32blk + 16s + 8(j>>2) + 4h + (j&3))
-// fp32: MFMA #(blk, r) takes X[blk][r] as is (k = lane>>5 <-> feature 32blk + RHO(r, lane>>5)).
 template <bool BF16, int KB>
-DEV void make_frags(Frags<BF16, KB>& F, const f32x16 (&X)[KB]) {
+DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
 #pragma unroll
   for (int blk = 0; blk < KB; ++blk) {
     if constexpr (BF16) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) F.f[2 * blk + s][j] = (__bf16)X[blk][8 * s + j];
+      for (int j = 0; j < 8; ++j) F.f[blk][j] = (__bf16)X[2 * blk + (j >> 2)][j & 3];
     } else {
-      F.f[blk] = X[blk];
+      F.f[2 * blk] = X[2 * blk];
+      F.f[2 * blk + 1] = X[2 * blk + 1];
     }
   }
 }
 
-// acc[m] += W^T[32m.., :] X  for MBS out-blocks whose fragments start at `lds`
-// (panel order: [m][blk][s or r4][lane] x 16 bytes; see enf_pack.hip).
-template <bool BF16, int KB, int MBS>
-DEV void gemm_stage(f32x16* acc, const Frags<BF16, KB>& F, const char* lds, int lane) {
+// acc[mt] += W^T[16 mt .., :] X for MTS out-tiles whose fragments start at `lds`.
+// Panel order (enf_pack.hip): bf16 [mt][blk][lane] x 16 B; fp32 [mt][in-tile][lane] x 16 B.
+template <bool BF16, int KB, int MTS>
+DEV void gemm_stage(f32x4* acc, const Frags<BF16, KB>& F, const char* lds, int lane) {
 #pragma unroll
-  for (int m = 0; m < MBS; ++m) {
+  for (int mt = 0; mt < MTS; ++mt) {
+    if constexpr (BF16) {
 #pragma unroll
-    for (int blk = 0; blk < KB; ++blk) {
-      if constexpr (BF16) {
+      for (int blk = 0; blk < KB; ++blk) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + (((mt * KB + blk) * 64 + lane) << 4));
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, F.f[blk], acc[mt], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + ((((m * KB + blk) * 2 + s) * 64 + lane) << 4));
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, F.f[2 * blk + s], acc[m], 0, 0, 0);
-        }
-      } else {
+      for (int tin = 0; tin < 2 * KB; ++tin) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lds + (((mt * 2 * KB + tin) * 64 + lane) << 4));
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + ((((m * KB + blk) * 4 + r4) * 64 + lane) << 4));
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], F.f[blk][4 * r4 + i], acc[m], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], F.f[tin][i], acc[mt], 0, 0, 0);
       }
     }
-    // keep the A-fragment ds_reads of later out-blocks from being hoisted above this block's MFMAs
-    // (the scheduler otherwise clusters them all up front and spills)
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <bool BF16> constexpr int frag_bytes() { return BF16 ? 2048 : 4096; }
-
-// per-row constant vector (bias, u, v0 ..) -> acc layout; `vec` is fp32 in LDS or global,
-// the address depends on the lane only through its half, so the read is a broadcast.
-DEV void load_rowvec(f32x16& acc, const float* vec, int blk, int half) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(vec + 32 * blk + 8 * g + 4 * half);
-    acc[4 * g + 0] = v[0]; acc[4 * g + 1] = v[1]; acc[4 * g + 2] = v[2]; acc[4 * g + 3] = v[3];
-  }
+// per-row constant vector (bias, u, v0 ..) -> one tile in acc layout; `vec` is fp32 in LDS or
+// global; the address depends on the lane only through its quad, so the read is a broadcast.
+DEV f32x4 rowvec(const float* vec, int tile, int quad) {
+  return *reinterpret_cast<const f32x4*>(vec + 16 * tile + 4 * quad);
 }
 
-// sum over both lane halves (the two halves of a column hold disjoint feature rows)
-DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// sum over the four quads of a column (they hold disjoint feature rows)
+DEV float xquad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
 
 // ------------------------------------------------------------------ math
 // gelu, tanh approximation (jax.nn.gelu default): 0.5x(1+tanh(c(x+0.044715x^3))) = x*sigmoid(2c(..))
@@ -118,11 +113,8 @@ template <bool FAST> DEV float cos_rev(float t) {
 }
 
 // ------------------------------------------------------------------ weight staging
-// All 256 threads copy one stage (<= STAGE_MAX bytes, multiple of 4 KB) global -> registers
-// (issue, before the compute that hides the latency) -> LDS (commit, after the compute).
 constexpr int STAGE_MAX = 32768;
 constexpr unsigned NO_STAGE = 0xFFFFFFFFu;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Stage sources are byte offsets into the packed blob.  A stage moves global -> LDS by LDS-DMA
 // (buffer_load_dwordx4 ... lds): each wave-instruction carries 1 KB (lane-linear, which is exactly
@@ -135,65 +127,74 @@ DEV __amdgpu_buffer_rsrc_t make_blob_rsrc(const char* blob, unsigned bytes) {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int BYTES>
+template <int BYTES, int NW = NWAVES>
 DEV void stage_issue(__amdgpu_buffer_rsrc_t rs, unsigned src_off, char* dst, int wave, int lane) {
-  static_assert(BYTES % 4096 == 0 && BYTES <= STAGE_MAX, "stage size");
+  static_assert(BYTES % 1024 == 0 && BYTES <= STAGE_MAX, "stage size");
+  constexpr int PIECES = BYTES / 1024;                  // 1 KB per wave-instruction
 #pragma unroll
-  for (int i = 0; i < BYTES / 4096; ++i) {
-    const int piece = (i * 4 + wave) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + piece), 16, lane * 16, src_off + piece, 0, 0);
+  for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+    const int piece = (i * NW + wave) * 1024;
+    if (PIECES % NW == 0 || piece < BYTES)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + piece), 16, lane * 16, src_off + piece, 0, 0);
   }
 }
 DEV void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Panel = (MBOUT out-blocks) x (KBIN in-blocks) of A-operand fragments, streamed through a
-// 2-slot LDS ring (slot stride STAGE_MAX) in stages of MBS out-blocks.
+// Panel = (MTOUT out-tiles of 16 rows) x (KBIN in-blocks of 32) of A-operand fragments, streamed
+// through a 2-slot LDS ring (slot stride STAGE_MAX) in stages of MTS out-tiles.
 struct Pipe { __amdgpu_buffer_rsrc_t rs; int cur; int wave; };
 
-template <int KBIN, int MBOUT, bool BF16> struct PanelCfg {
-  static constexpr int FRAG = BF16 ? 2048 : 4096;
-  static constexpr int MBLK_BYTES = KBIN * FRAG;
-  static constexpr int MBS = (STAGE_MAX / MBLK_BYTES) < MBOUT ? (STAGE_MAX / MBLK_BYTES) : MBOUT;
-  static_assert(MBS >= 1 && MBOUT % MBS == 0, "panel staging");
-  static constexpr int SPP = MBOUT / MBS;           // stages per panel
-  static constexpr int STAGE = MBS * MBLK_BYTES;    // bytes per stage
-  static constexpr int BYTES = MBOUT * MBLK_BYTES;
+template <int KBIN, int MTOUT, bool BF16> struct PanelCfg {
+  static constexpr int MT_BYTES = KBIN * (BF16 ? 1024 : 2048);
+  static constexpr int MTS = (STAGE_MAX / MT_BYTES) < MTOUT ? (STAGE_MAX / MT_BYTES) : MTOUT;
+  static_assert(MTS >= 1 && MTOUT % MTS == 0, "panel staging");
+  static constexpr int SPP = MTOUT / MTS;           // stages per panel
+  static constexpr int STAGE = MTS * MT_BYTES;      // bytes per stage
+  static constexpr int BYTES = MTOUT * MT_BYTES;
 };
 
-// acc[MBOUT] += panel . F.  Precondition: the panel's first stage is resident in ring[cur] and
+// acc[MTOUT] += panel . F.  Precondition: the panel's first stage is resident in ring[cur] and
 // visible (a barrier has passed).  While stage s is multiplied, stage s+1 (or the first stage of
 // `next`, NEXT_BYTES long; NO_STAGE = nothing follows) streams into the other ring slot; one
 // wait + one barrier per stage publish it.  `panel` / `next` are blob byte offsets (wave-uniform).
 // `active` (wave-uniform) lets a wave without work keep the staging / barrier cadence.
-template <int KBIN, int MBOUT, bool BF16, int NEXT_BYTES>
-DEV void panel_gemm(f32x16 (&acc)[MBOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel,
-                    unsigned next, bool active, int tid, int lane) {
-  using C = PanelCfg<KBIN, MBOUT, BF16>;
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES>
+DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned next,
+                    bool active, int lane) {
+  using C = PanelCfg<KBIN, MTOUT, BF16>;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
-    if (active) gemm_stage<BF16, KBIN, C::MBS>(&acc[sp * C::MBS], F, ring + P.cur * STAGE_MAX, lane);
+    if (sp + 1 < C::SPP) stage_issue<C::STAGE, NW>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    else if (next != NO_STAGE) stage_issue<NEXT_BYTES, NW>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    if (active) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane);
     stage_wait();
     __syncthreads();
     P.cur ^= 1;
   }
 }
 
-// LayerNorm statistics over the KB*32 features of this lane's column (biased variance, eps 1e-6)
-template <int KB> DEV void ln_stats(const f32x16 (&X)[KB], float& mu, float& rstd) {
+template <int BYTES, int NW = NWAVES> DEV void first_stage(Pipe& P, char* ring, unsigned panel, int wave, int lane) {
+  P.cur = 0;
+  P.wave = __builtin_amdgcn_readfirstlane(wave);
+  stage_issue<BYTES, NW>(P.rs, panel, ring, P.wave, lane);
+  stage_wait();
+  __syncthreads();
+}
+
+// LayerNorm statistics over the NT*16 features of this lane's column (biased variance, eps 1e-6)
+template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd) {
   float s = 0.f;
 #pragma unroll
-  for (int b = 0; b < KB; ++b)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += X[b][r];
-  mu = xhalf_sum(s) * (1.0f / (32 * KB));
+    for (int i = 0; i < 4; ++i) s += X[t][i];
+  mu = xquad_sum(s) * (1.0f / (16 * NT));
   float q = 0.f;
 #pragma unroll
-  for (int b = 0; b < KB; ++b)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float t = X[b][r] - mu; q = fmaf(t, t, q); }
-  rstd = rsqrtf(xhalf_sum(q) * (1.0f / (32 * KB)) + 1e-6f);
+    for (int i = 0; i < 4; ++i) { const float d = X[t][i] - mu; q = fmaf(d, d, q); }
+  rstd = rsqrtf(xquad_sum(q) * (1.0f / (16 * NT)) + 1e-6f);
 }
 
 // ------------------------------------------------------------------ invariants + window
@@ -201,6 +202,14 @@ template <int KB> DEV void ln_stats(const f32x16 (&X)[KB], float& mu, float& rst
 // table: periodic/rel/abs/norm -> (p0,p1,p2,-); ponita -> (px,py,cos t,sin t);
 // sphere -> (phi, theta, sin theta, cos theta).  sx/cx = sin/cos(theta_x) (sphere only).
 struct QueryPt { float x0, x1, x2, sx, cx; };
+
+DEV QueryPt load_query(const float* xp, int dx, int inv_id) {
+  QueryPt q;
+  q.x0 = xp[0]; q.x1 = dx > 1 ? xp[1] : 0.f; q.x2 = dx > 2 ? xp[2] : 0.f;
+  q.sx = 0.f; q.cx = 0.f;
+  if (inv_id == ENF_INV_LATITUDE_PERIODIC || inv_id == ENF_INV_POLAR_PERIODIC) { q.sx = sinf(q.x1); q.cx = cosf(q.x1); }
+  return q;
+}
 
 template <bool FAST>
 DEV void pair_invariant(int inv_id, int dx, const QueryPt& q, const f32x4& pz, float wcoef, int use_window,

@@ -4,7 +4,7 @@
 //   * fp32 row-major matrices/vectors used by the latent prologue (per-latent work, VALU),
 //   * fp32 bias / constant vectors used as accumulator initialisers in the per-pair chain,
 //   * the per-pair and per-query weight panels in MFMA A-operand fragment order
-//     ("panel": out-blocks x in-blocks x fragment), bf16 or fp32 depending on EnfDesc.precision,
+//     ("panel": 16-row out-tiles x 32-wide in-blocks x 1 KB fragments), bf16 or fp32 (EnfDesc.precision),
 //   * the same panels transposed for the backward chain (dX = W dY),
 //   * plain fp32 copies of every folded matrix (inputs of the panel packer).
 // Folds (exact algebra, fp32; DESIGN.md "Folds"):
@@ -67,18 +67,15 @@ inline EnfDims enf_dims(const EnfDesc* d) {
   return m;
 }
 
-// bytes of one (out-block, in-block) fragment group: 32x32 weights
-ENF_HD inline size_t enf_frag_bytes(int bf16) { return bf16 ? 2048 : 4096; }
-ENF_HD inline size_t enf_panel_bytes(int out_blocks, int in_blocks, int bf16) {
-  return (size_t)out_blocks * in_blocks * enf_frag_bytes(bf16);
-}
+// bytes of a packed panel with R output rows (multiple of 16) and K inputs (multiple of 32)
+ENF_HD inline size_t enf_panel_bytes(int R, int K, int bf16) { return (size_t)R * K * (bf16 ? 2 : 4); }
 
 struct EnfLayout {
   // ---- prologue, fp32 row-major (in,out)
   size_t stem_w, stem_b, lna_g, lna_b, wk, bk, wv, bv;
   size_t mu;     // H x (D x D): u_h[i] = sum_d mu[h][i][d] * k_h[d]
   size_t cvec;   // H x D:       c_h    = sum_d cvec[h][d] * k_h[d]
-  // ---- coefficient A-operands of t = coeff^T inv (fp32 32x32x2 MFMA), [D/64 blocks][2 k-pairs][64 lanes]
+  // ---- coefficient A-operands of t = coeff^T inv (fp32 16x16x4 MFMA), [D/32 t-tiles][64 lanes]
   size_t acq, acv;
   // ---- accumulator-init vectors, fp32
   size_t bq1, bv1, bf, bgb, bm;         // D, D, D, 2HD (panel order), D
@@ -108,25 +105,25 @@ inline EnfLayout enf_layout(const EnfDims& m) {
   L.stem_w = take(f * C * D); L.stem_b = take(f * D); L.lna_g = take(f * D); L.lna_b = take(f * D);
   L.wk = take(f * D * HD); L.bk = take(f * HD); L.wv = take(f * D * HD); L.bv = take(f * HD);
   L.mu = take(f * H * D * D); L.cvec = take(f * H * D);
-  L.acq = take(f * (D / 64) * 2 * 64); L.acv = take(f * (D / 64) * 2 * 64);
+  L.acq = take(f * (D / 32) * 64); L.acv = take(f * (D / 32) * 64);   // D/32 t-tiles x 64 lanes
   L.bq1 = take(f * D); L.bv1 = take(f * D); L.bf = take(f * D); L.bgb = take(f * 2 * HD); L.bm = take(f * D);
   L.bB = take(f * HD); L.bF1 = take(f * HD); L.bO0 = take(f * D); L.bO2 = take(f * D); L.bO4 = take(f * 32 * m.OB);
-  const int KB = m.KB, KBH = m.KBH, OB = m.OB, bf = m.bf16;
-  L.aq1 = take(enf_panel_bytes(KB, KB, bf)); L.av1 = take(enf_panel_bytes(KB, KB, bf));
-  L.af = take(enf_panel_bytes(KB, KB, bf)); L.agb = take(enf_panel_bytes(2 * H * KB, KB, bf));
-  L.am = take(enf_panel_bytes(KB, KB, bf));
-  L.atb = take(enf_panel_bytes(KBH, KBH, bf)); L.atf1 = take(enf_panel_bytes(KBH, KBH, bf));
-  L.ato0 = take(enf_panel_bytes(KB, KBH, bf)); L.ato2 = take(enf_panel_bytes(KB, KB, bf));
-  L.ato4 = take(enf_panel_bytes(OB, KB, bf));
-  L.gq1 = take(enf_panel_bytes(KB, KB, bf)); L.gv1 = take(enf_panel_bytes(KB, KB, bf));
-  L.gf = take(enf_panel_bytes(KB, KB, bf)); L.ggb = take(enf_panel_bytes(KB, 2 * H * KB, bf));
-  L.gm = take(enf_panel_bytes(KB, KB, bf));
-  L.gcq = take(enf_panel_bytes(1, D / 64, bf)); L.gcv = take(enf_panel_bytes(1, D / 64, bf));
-  L.gtb = take(enf_panel_bytes(KBH, KBH, bf)); L.gtf1 = take(enf_panel_bytes(KBH, KBH, bf));
-  L.gto0 = take(enf_panel_bytes(KBH, KB, bf)); L.gto2 = take(enf_panel_bytes(KB, KB, bf));
-  L.gto4 = take(enf_panel_bytes(KB, OB, bf));
+  const int bf = m.bf16, OP = 32 * m.OB;
+  L.aq1 = take(enf_panel_bytes(D, D, bf)); L.av1 = take(enf_panel_bytes(D, D, bf));
+  L.af = take(enf_panel_bytes(D, D, bf)); L.agb = take(enf_panel_bytes(2 * HD, D, bf));
+  L.am = take(enf_panel_bytes(D, D, bf));
+  L.atb = take(enf_panel_bytes(HD, HD, bf)); L.atf1 = take(enf_panel_bytes(HD, HD, bf));
+  L.ato0 = take(enf_panel_bytes(D, HD, bf)); L.ato2 = take(enf_panel_bytes(D, D, bf));
+  L.ato4 = take(enf_panel_bytes(OP, D, bf));
+  L.gq1 = take(enf_panel_bytes(D, D, bf)); L.gv1 = take(enf_panel_bytes(D, D, bf));
+  L.gf = take(enf_panel_bytes(D, D, bf)); L.ggb = take(enf_panel_bytes(D, 2 * HD, bf));
+  L.gm = take(enf_panel_bytes(D, D, bf));
+  L.gcq = take(enf_panel_bytes(16, D / 2, bf)); L.gcv = take(enf_panel_bytes(16, D / 2, bf));
+  L.gtb = take(enf_panel_bytes(HD, HD, bf)); L.gtf1 = take(enf_panel_bytes(HD, HD, bf));
+  L.gto0 = take(enf_panel_bytes(HD, D, bf)); L.gto2 = take(enf_panel_bytes(D, D, bf));
+  L.gto4 = take(enf_panel_bytes(D, OP, bf));
   L.p_af = take(f * D * D); L.p_agb = take(f * D * 2 * HD); L.p_wb = take(f * HD * HD);
-  L.p_wf1 = take(f * HD * HD); L.p_tmp = take(f * HD * HD); L.p_o4 = take(f * D * 32 * OB);
+  L.p_wf1 = take(f * HD * HD); L.p_tmp = take(f * HD * HD); L.p_o4 = take(f * D * OP);
   L.p_mxw = take(f * D * D); L.p_mxb = take(f * D);
   L.total = o;
   return L;

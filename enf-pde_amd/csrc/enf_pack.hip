@@ -46,40 +46,44 @@ __global__ void padcopy_kernel(float* dst, const float* src, int rows, int cols,
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (j < cols_pad && i < rows) dst[(size_t)i * cols_pad + j] = j < cols ? src[(size_t)i * cols + j] : 0.f;
 }
-// RFF coefficient A-operand of t = coeff^T inv (v_mfma_f32_32x32x2_f32): [m][kk][lane]
+// RFF coefficient A-operand of t = coeff^T inv (v_mfma_f32_16x16x4_f32, K = 4 = the I <= 4 invariant
+// components): [t-tile][lane], lane (i = lane&15, q = lane>>4) holds coeff[q][16 tt + i]
 __global__ void coef_frag_kernel(float* dst, const float* coeff, int I, int Dh /*D/2*/) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = (Dh / 32) * 2 * 64;
+  const int total = (Dh / 16) * 64;
   if (idx >= total) return;
-  const int lane = idx & 63, kk = (idx >> 6) & 1, m = idx >> 7;
-  const int c = 2 * kk + (lane >> 5), t = 32 * m + (lane & 31);
+  const int lane = idx & 63, tt = idx >> 6;
+  const int c = lane >> 4, t = 16 * tt + (lane & 15);
   dst[idx] = c < I ? coeff[(size_t)c * Dh + t] : 0.f;
 }
 
 // ---------------------------------------------------------------- MFMA A-operand panel packer
-// A[r][k] (R x K, both multiples of 32) = trans ? W[r*ldw + k] : W[k*ldw + r].
-// bf16: byte (((m*KBin+blk)*2+s)*64+lane)*16 + 2j  <- A[32m + (lane&31)][32blk + 16s + 8(j>>2) + 4(lane>>5) + (j&3)]
-// fp32: byte (((m*KBin+blk)*4+r4)*64+lane)*16 + 4i <- A[32m + (lane&31)][32blk + 8 r4 + 4(lane>>5) + i]
-// (the k order is the one in which a 32x32 accumulator presents its rows as the next B operand)
+// A[r][k] (R x K; R multiple of 16, K multiple of 32) = scale * (trans ? W[r*ldw + k] : W[k*ldw + r]).
+// bf16 (v_mfma_f32_16x16x32_bf16): byte ((mt*KB+blk)*64+lane)*16 + 2j
+//        <- A[16mt + (lane&15)][32blk + 16(j>>2) + 4(lane>>4) + (j&3)]
+// fp32 (v_mfma_f32_16x16x4_f32):   byte ((mt*2KB+tin)*64+lane)*16 + 4i
+//        <- A[16mt + (lane&15)][16tin + 4(lane>>4) + i]
+// (the k order is the one in which 16x16 accumulator tiles present their rows as the next B operand)
 __global__ void pack_panel_kernel(void* dst, const float* W, int ldw, int R, int K, int trans, int bf16,
                                   int Rvalid, int Kvalid, float scale) {
-  const int KBin = K / 32;
   const size_t total = (size_t)R * K;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   int r, k;
   if (bf16) {
-    const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1;
-    const size_t g = e >> 10;  // m*KBin + blk
-    const int blk = g % KBin, m = g / KBin;
-    r = 32 * m + (lane & 31);
-    k = 32 * blk + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+    const int KB = K / 32;
+    const int j = e & 7, lane = (e >> 3) & 63;
+    const size_t g = e >> 9;  // mt*KB + blk
+    const int blk = g % KB, mt = g / KB;
+    r = 16 * mt + (lane & 15);
+    k = 32 * blk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
   } else {
-    const int i = e & 3, lane = (e >> 2) & 63, r4 = (e >> 8) & 3;
-    const size_t g = e >> 10;
-    const int blk = g % KBin, m = g / KBin;
-    r = 32 * m + (lane & 31);
-    k = 32 * blk + 8 * r4 + 4 * (lane >> 5) + i;
+    const int KT = K / 16;
+    const int i = e & 3, lane = (e >> 2) & 63;
+    const size_t g = e >> 8;  // mt*KT + tin
+    const int tin = g % KT, mt = g / KT;
+    r = 16 * mt + (lane & 15);
+    k = 16 * tin + 4 * (lane >> 4) + i;
   }
   float v = 0.f;
   if (r < Rvalid && k < Kvalid) v = scale * (trans ? W[(size_t)r * ldw + k] : W[(size_t)k * ldw + r]);
@@ -137,7 +141,7 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
   }
   // ---- RFF coefficient fragments
   {
-    const int tot = (D / 64) * 2 * 64;
+    const int tot = (D / 32) * 64;
     hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, F(L.acq), T[ENF_W_RQ_COEF], I, D / 2);
     hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, F(L.acv), T[ENF_W_RV_COEF], I, D / 2);
   }
@@ -181,10 +185,10 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
   if ((rc = pack_panel(st, blob, L.gv1, T[ENF_W_RV_W1], D, D, D, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gf, F(L.p_af), D, D, D, 1, bf))) return rc;
   for (int h = 0; h < H; ++h)   // one K-slice (that head's [g b g b ..] 2D columns) per head
-    if ((rc = pack_panel(st, blob, L.ggb + (size_t)h * enf_panel_bytes(m.KB, 2 * m.KB, bf), F(L.p_agb) + h * 2 * D, 2 * HD, D, 2 * D, 1, bf))) return rc;
+    if ((rc = pack_panel(st, blob, L.ggb + (size_t)h * enf_panel_bytes(D, 2 * D, bf), F(L.p_agb) + h * 2 * D, 2 * HD, D, 2 * D, 1, bf))) return rc;
   // d inv[c] = sum_t 2 pi coeff[c][t] d t[t]  (RFF:92)
-  if ((rc = pack_panel(st, blob, L.gcq, T[ENF_W_RQ_COEF], D / 2, 32, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
-  if ((rc = pack_panel(st, blob, L.gcv, T[ENF_W_RV_COEF], D / 2, 32, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
+  if ((rc = pack_panel(st, blob, L.gcq, T[ENF_W_RQ_COEF], D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
+  if ((rc = pack_panel(st, blob, L.gcv, T[ENF_W_RV_COEF], D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
   if ((rc = pack_panel(st, blob, L.gm, T[ENF_W_MX_W0], D, D, D, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gtb, F(L.p_wb), HD, HD, HD, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gtf1, F(L.p_wf1), HD, HD, HD, 1, bf))) return rc;

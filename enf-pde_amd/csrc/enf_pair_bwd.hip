@@ -2,7 +2,7 @@
 // (u, v0, c, pose, window coefficient), i.e. the part of jax.grad(loss)(latents)
 // (pde_trainer.py:188,200) that touches every (query, latent) pair.
 //
-// "z-major": one wave owns ONE latent z of one signal and sweeps tiles of 32 queries
+// "z-major": one wave owns ONE latent z of one signal and sweeps tiles of 16 queries
 // (columns = queries).  Everything per pair is recomputed in registers (nothing of size
 // B*N*Z is ever stored); reductions over queries -- the gradient of a per-latent quantity --
 // stay lane-local across the sweep and are folded across lanes once, at the end.
@@ -11,8 +11,9 @@
 //     att = exp(logit - lse),  d(logit) = att * (d(ybar).n~ - delta).
 // Per tile (H heads):  q-forward (logits) -> v-forward to n^ -> per head {gamma/beta, mixer
 // forward, mixer backward, FiLM backward, gamma/beta backward} -> LN/gelu/relu backward to the
-// value RFF -> q-branch recompute + backward -> invariant Jacobian.  608 MFMAs (32x32x16 bf16)
-// per tile at D=128, H=2 against 288 in the forward.
+// value RFF -> q-branch recompute + backward -> invariant Jacobian.  608 MFMAs (16x16x32 bf16)
+// per tile at D=128, H=2 against 288 in the forward.  4 waves per workgroup (one per SIMD): the
+// per-lane partial sums (d u, d v0) need the 512-register budget.
 #include <hip/hip_runtime.h>
 #include "enf_layout.h"
 #include "enf_device.h"
@@ -26,53 +27,27 @@ struct PairBwdArgs {
   int B, N, Z, dx, inv, use_window, nsplit;
 };
 
+constexpr int BW = 4;                 // waves per workgroup in this kernel
+constexpr int BTHREADS = 64 * BW;
+
 template <int D, int H, bool BF16> struct PairBwdSmem {
-  static constexpr int TB = D / 64;
   static constexpr int RING = 0;
   static constexpr int CONSTS = RING + 2 * STAGE_MAX;
-  // bq1 bv1 bf bm (D each) | bgb (2HD) | acq acv ((D/64)*128 each)
-  static constexpr int N_CONST = 4 * D + 2 * H * D + 2 * (D / 64) * 128;
+  // bq1 bv1 bf bm (D each) | bgb (2HD) | acq acv (2D each)
+  static constexpr int N_CONST = 4 * D + 2 * H * D + 4 * D;
   static constexpr int GC = CONSTS + 4 * N_CONST;                          // gcq | gcv panels
-  static constexpr int GC_BYTES = PanelCfg<TB, 1, BF16>::BYTES;
-  static constexpr int ZVEC = GC + 2 * GC_BYTES;                           // 4 waves x 2HD floats
-  static constexpr int TOTAL = ZVEC + 4 * 4 * 2 * H * D;
+  static constexpr int GC_BYTES = PanelCfg<D / 64, 1, BF16>::BYTES;
+  static constexpr int ZVEC = GC + 2 * GC_BYTES;                           // BW waves x 2HD floats
+  static constexpr int TOTAL = ZVEC + 4 * BW * 2 * H * D;
 };
 
-// gamma/beta panel that also returns 1+gamma (needed by d v0) -- same staging as gb_panel
-template <int D, bool BF16, int NEXT_BYTES>
-DEV void gb_panel_keep(f32x16 (&v)[D / 32], f32x16 (&opg)[D / 32], const Frags<BF16, D / 32>& F, Pipe& P, char* ring,
-                       unsigned panel, unsigned next, const float* bias, const float* v0vec, int tid, int lane, int half) {
-  using C = typename PairCfg<D, BF16>::GB;
-  constexpr int KB = D / 32, MBS = C::MBS;
-#pragma unroll
-  for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
-    f32x16 t[MBS];
-#pragma unroll
-    for (int j = 0; j < MBS; ++j) load_rowvec(t[j], bias, sp * MBS + j, half);
-    gemm_stage<BF16, KB, MBS>(t, F, ring + P.cur * STAGE_MAX, lane);
-#pragma unroll
-    for (int j = 0; j < MBS / 2; ++j) {
-      const int m = sp * (MBS / 2) + j;
-      f32x16 v0;
-      load_rowvec(v0, v0vec, m, half);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { opg[m][r] = 1.0f + t[2 * j][r]; v[m][r] = fmaf(v0[r], opg[m][r], t[2 * j + 1][r]); }
-    }
-    stage_wait();
-    __syncthreads();
-    P.cur ^= 1;
-  }
-}
-
 // d t = d E_sin * E_cos - d E_cos * E_sin   (the 2 pi is folded into the gc panel)
-template <int D> DEV void rff_embed_bwd(f32x16 (&dT)[D / 64], const f32x16 (&dE)[D / 32], const f32x16 (&E)[D / 32]) {
-  constexpr int TB = D / 64;
+template <int D> DEV void rff_embed_bwd(f32x4 (&dT)[D / 32], const f32x4 (&dE)[D / 16], const f32x4 (&E)[D / 16]) {
+  constexpr int TT = D / 32;
 #pragma unroll
-  for (int m = 0; m < TB; ++m)
+  for (int m = 0; m < TT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dT[m][r] = dE[m][r] * E[TB + m][r] - dE[TB + m][r] * E[m][r];
+    for (int i = 0; i < 4; ++i) dT[m][i] = dE[m][i] * E[TT + m][i] - dE[TT + m][i] * E[m][i];
 }
 
 // Jacobian of (invariant, window) w.r.t. the latent pose row and the window coefficient.
@@ -146,35 +121,35 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
 }
 
 template <int D, int H, bool BF16>
-__global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
+__global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
   using Cfg = PairCfg<D, BF16>;
   using SM = PairBwdSmem<D, H, BF16>;
-  constexpr int KB = Cfg::KB, TB = D / 64;
+  constexpr int KB = Cfg::KB, NT = Cfg::NT, TT = D / 32;
   constexpr int ST_DD = Cfg::DD::STAGE, ST_GB = Cfg::GB::STAGE, PANEL_GB = Cfg::GB::BYTES;
-  using GG = PanelCfg<2 * KB, KB, BF16>;              // one head's d n^ += AGB_h [dgamma; dbeta]
+  using GG = PanelCfg<2 * KB, NT, BF16>;              // one head's d n^ += AGB_h [dgamma; dbeta]
   constexpr int ST_GG = GG::STAGE, PANEL_GG = GG::BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem + SM::RING;
   float* cst = reinterpret_cast<float*>(smem + SM::CONSTS);
   float* c_bq1 = cst, *c_bv1 = cst + D, *c_bf = cst + 2 * D, *c_bm = cst + 3 * D, *c_bgb = cst + 4 * D;
-  float* c_acq = c_bgb + 2 * H * D, *c_acv = c_acq + (D / 64) * 128;
+  float* c_acq = c_bgb + 2 * H * D, *c_acv = c_acq + 2 * D;
   char* gcq = smem + SM::GC, *gcv = gcq + SM::GC_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, quad = lane >> 4;
   float* zv = reinterpret_cast<float*>(smem + SM::ZVEC) + wave * 2 * H * D;
   const char* blob = A.blob;
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
-  const int bz = blockIdx.x * 4 + wave;
+  const int bz = blockIdx.x * BW + wave;
   const bool active = bz < A.B * A.Z;
   const int bzc = active ? bz : A.B * A.Z - 1;
   const int b = bzc / A.Z;
   const int split = blockIdx.y;
 
-  for (int i = tid; i < D; i += 256) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
-  for (int i = tid; i < 2 * H * D; i += 256) c_bgb[i] = G(A.L.bgb)[i];
-  for (int i = tid; i < (D / 64) * 128; i += 256) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
-  for (int i = tid; i < SM::GC_BYTES / 4; i += 256) {
+  for (int i = tid; i < D; i += BTHREADS) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
+  for (int i = tid; i < 2 * H * D; i += BTHREADS) c_bgb[i] = G(A.L.bgb)[i];
+  for (int i = tid; i < 2 * D; i += BTHREADS) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
+  for (int i = tid; i < SM::GC_BYTES / 4; i += BTHREADS) {
     reinterpret_cast<float*>(gcq)[i] = G(A.L.gcq)[i];
     reinterpret_cast<float*>(gcv)[i] = G(A.L.gcv)[i];
   }
@@ -194,39 +169,27 @@ __global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
                  gGB = (unsigned)A.L.ggb, gM = (unsigned)A.L.gm;
 
   Pipe P;
-  P.cur = 0;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
-  P.wave = __builtin_amdgcn_readfirstlane(wave);
-  stage_issue<ST_DD>(P.rs, pQ1, ring, P.wave, lane);
-  stage_wait();
-  __syncthreads();
+  first_stage<ST_DD, BW>(P, ring, pQ1, wave, lane);
 
   // per-lane partial sums over this wave's queries
-  f32x16 dU[H][KB], dV0[H][KB];
+  f32x4 dU[H][NT], dV0[H][NT];
   float dC[H], dpose[4] = {0.f, 0.f, 0.f, 0.f}, dwc = 0.f;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     dC[h] = 0.f;
 #pragma unroll
-    for (int k = 0; k < KB; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dU[h][k][r] = 0.f; dV0[h][k][r] = 0.f; }
+    for (int t = 0; t < NT; ++t) { dU[h][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dV0[h][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
 
-  const int ntiles = (A.N + 31) / 32;
+  const int ntiles = (A.N + 15) / 16;
   const int my_tiles = (ntiles - split + A.nsplit - 1) / A.nsplit;     // tiles split, split+nsplit, ..
   for (int ti = 0; ti < my_tiles; ++ti) {
-    const int n0 = (split + ti * A.nsplit) * 32;
+    const int n0 = (split + ti * A.nsplit) * 16;
     const bool nvalid = n0 + col < A.N;
     const int n = min(n0 + col, A.N - 1);
     const size_t qrow = (size_t)b * A.N + n;
-    QueryPt q;
-    {
-      const float* xp = A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx;
-      q.x0 = xp[0]; q.x1 = A.dx > 1 ? xp[1] : 0.f; q.x2 = A.dx > 2 ? xp[2] : 0.f;
-      q.sx = 0.f; q.cx = 0.f;
-      if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) { q.sx = sinf(q.x1); q.cx = cosf(q.x1); }
-    }
+    const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
     float inv[4], win;
     pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win);
 
@@ -234,159 +197,149 @@ __global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
     float att[H], dlogit[H];
     Frags<BF16, KB> F;
     {
-      f32x16 E[KB];
-      rff_embed<D, BF16>(E, inv, c_acq, lane, half);
-      make_frags<BF16, KB>(F, E);
-      f32x16 acc[KB];
+      f32x4 acc[NT];
+      rff_embed<D, BF16>(acc, inv, c_acq, lane, quad);
+      make_frags<BF16, KB>(F, acc);
 #pragma unroll
-      for (int k = 0; k < KB; ++k) load_rowvec(acc[k], c_bq1, k, half);
-      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, pQ1, pV1, true, tid, lane);
+      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
+      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, pQ1, pV1, true, lane);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-          f32x16 u;
-          load_rowvec(u, zv + h * D, k, half);
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 u = rowvec(zv + h * D, t, quad);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s = fmaf(fmaxf(acc[k][r], 0.f), u[r], s);
+          for (int i = 0; i < 4; ++i) s = fmaf(fmaxf(acc[t][i], 0.f), u[i], s);
         }
-        const float lg = xhalf_sum(s) + cz[h] + win;
+        const float lg = xquad_sum(s) + cz[h] + win;
         att[h] = __expf(lg - A.lse[qrow * H + h]);
       }
     }
     // ---------------- v-forward to the normalised f
-    f32x16 Ev[KB];                       // value-branch RFF features (needed again by d t)
-    rff_embed<D, BF16>(Ev, inv, c_acv, lane, half);
-    unsigned long long relu_mask = 0ull; // bit (16k + r): a2[k][r] > 0
-    f32x16 a3[KB], nh[KB];
+    unsigned relu_mask = 0u;             // bit (4t + i): a2[t][i] > 0
+    f32x4 a3[NT], nh[NT];
     float mu1, r1;
     {
-      make_frags<BF16, KB>(F, Ev);
-      f32x16 acc[KB];
+      f32x4 acc[NT];
+      rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
+      make_frags<BF16, KB>(F, acc);
 #pragma unroll
-      for (int k = 0; k < KB; ++k) load_rowvec(acc[k], c_bv1, k, half);
-      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, pV1, pF, true, tid, lane);
+      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bv1, t, quad);
+      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, pV1, pF, true, lane);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (acc[k][r] > 0.f) relu_mask |= 1ull << (16 * k + r);
-          acc[k][r] = fmaxf(acc[k][r], 0.f);
+        for (int i = 0; i < 4; ++i) {
+          if (acc[t][i] > 0.f) relu_mask |= 1u << (4 * t + i);
+          acc[t][i] = fmaxf(acc[t][i], 0.f);
         }
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
-      for (int k = 0; k < KB; ++k) load_rowvec(a3[k], c_bf, k, half);
-      panel_gemm<KB, KB, BF16, ST_GB>(a3, F, P, ring, pF, pGB, true, tid, lane);
+      for (int t = 0; t < NT; ++t) a3[t] = rowvec(c_bf, t, quad);
+      panel_gemm<KB, NT, BF16, ST_GB, BW>(a3, F, P, ring, pF, pGB, true, lane);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nh[k][r] = gelu_f(a3[k][r]);
-      ln_stats<KB>(nh, mu1, r1);
+        for (int i = 0; i < 4; ++i) nh[t][i] = gelu_f(a3[t][i]);
+      ln_stats<NT>(nh, mu1, r1);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nh[k][r] = (nh[k][r] - mu1) * r1;
+        for (int i = 0; i < 4; ++i) nh[t][i] = (nh[t][i] - mu1) * r1;
       make_frags<BF16, KB>(F, nh);
     }
-    f32x16 dnh[KB];                      // d n^ accumulated over heads
+    f32x4 dnh[NT];                       // d n^ accumulated over heads
 #pragma unroll
-    for (int k = 0; k < KB; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dnh[k][r] = 0.f;
+    for (int t = 0; t < NT; ++t) dnh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      f32x16 v[KB], opg[KB];
-      gb_panel_keep<D, BF16, ST_DD>(v, opg, F, P, ring, pGB + h * PANEL_GB, pM, c_bgb + 2 * h * D, zv + H * D + h * D, tid,
-                                    lane, half);
-      f32x16 a5[KB];
+      f32x4 v[NT], opg[NT];
+      gb_panel<D, BF16, ST_DD, true, BW>(v, opg, F, P, ring, pGB + h * PANEL_GB, pM, true, c_bgb + 2 * h * D,
+                                         zv + H * D + h * D, lane, quad);
+      f32x4 a5[NT];
       {
         Frags<BF16, KB> FV;
         make_frags<BF16, KB>(FV, v);
 #pragma unroll
-        for (int k = 0; k < KB; ++k) load_rowvec(a5[k], c_bm, k, half);
-        panel_gemm<KB, KB, BF16, ST_DD>(a5, FV, P, ring, pM, gM, true, tid, lane);
+        for (int t = 0; t < NT; ++t) a5[t] = rowvec(c_bm, t, quad);
+        panel_gemm<KB, NT, BF16, ST_DD, BW>(a5, FV, P, ring, pM, gM, true, lane);
       }
       // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
       float mu2, r2;
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[k][r] = gelu_f(a5[k][r]);
-      ln_stats<KB>(v, mu2, r2);
+        for (int i = 0; i < 4; ++i) v[t][i] = gelu_f(a5[t][i]);
+      ln_stats<NT>(v, mu2, r2);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[k][r] = (v[k][r] - mu2) * r2;
+        for (int i = 0; i < 4; ++i) v[t][i] = (v[t][i] - mu2) * r2;
       // d n~ = att * d ybar ;  d att = d ybar . n~ ;  softmax backward with the forward's lse / delta
-      f32x16 dy[KB];
+      f32x4 dy[NT];
       {
         const float* dyrow = A.dybar + qrow * (H * D) + h * D;
 #pragma unroll
-        for (int k = 0; k < KB; ++k)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(dyrow + 32 * k + 8 * g + 4 * half);
-            dy[k][4 * g] = t[0]; dy[k][4 * g + 1] = t[1]; dy[k][4 * g + 2] = t[2]; dy[k][4 * g + 3] = t[3];
-          }
+        for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t + 4 * quad);
       }
       float s0 = 0.f;
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s0 = fmaf(dy[k][r], v[k][r], s0);
-      const float datt = xhalf_sum(s0);
+        for (int i = 0; i < 4; ++i) s0 = fmaf(dy[t][i], v[t][i], s0);
+      const float datt = xquad_sum(s0);
       dlogit[h] = nvalid ? att[h] * (datt - A.delta[qrow * H + h]) : 0.f;
       const float ah = nvalid ? att[h] : 0.f;
       // LayerNorm backward (d n~ = ah * dy), then gelu backward
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dy[k][r] *= ah; s1 += dy[k][r]; s2 = fmaf(dy[k][r], v[k][r], s2); }
-      const float m1 = xhalf_sum(s1) * (1.0f / D), m2 = xhalf_sum(s2) * (1.0f / D);
+        for (int i = 0; i < 4; ++i) { dy[t][i] *= ah; s1 += dy[t][i]; s2 = fmaf(dy[t][i], v[t][i], s2); }
+      const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dy[k][r] = r2 * (dy[k][r] - m1 - v[k][r] * m2) * gelu_grad_f(a5[k][r]);   // d a5
+        for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * gelu_grad_f(a5[t][i]);   // d a5
       // d v = AM d a5
       {
         Frags<BF16, KB> FA;
         make_frags<BF16, KB>(FA, dy);
 #pragma unroll
-        for (int k = 0; k < KB; ++k)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[k][r] = 0.f;
-        panel_gemm<KB, KB, BF16, ST_GG>(v, FA, P, ring, gM, gGB + h * PANEL_GG, true, tid, lane);               // v <- d v
+        for (int t = 0; t < NT; ++t) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        panel_gemm<KB, NT, BF16, ST_GG, BW>(v, FA, P, ring, gM, gGB + h * PANEL_GG, true, lane);               // v <- d v
       }
-      // FiLM backward: d v0 += d v (1+gamma); d gamma = d v * v0; d beta = d v
+      // FiLM backward: d v0 += d v (1+gamma); d gamma = d v * v0; d beta = d v.
+      // B operand of the [g g b b]-ordered panel: block 2m = d gamma (tiles 2m, 2m+1), block 2m+1 = d beta
       Frags<BF16, 2 * KB> FG;
 #pragma unroll
-      for (int k = 0; k < KB; ++k) {
-        f32x16 v0;
-        load_rowvec(v0, zv + H * D + h * D, k, half);
-        f32x16 dgam;
+      for (int m = 0; m < KB; ++m) {
+        f32x4 dg[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dV0[h][k][r] = fmaf(v[k][r], opg[k][r], dV0[h][k][r]);
-          dgam[r] = v[k][r] * v0[r];
+        for (int e = 0; e < 2; ++e) {
+          const int t = 2 * m + e;
+          const f32x4 v0 = rowvec(zv + H * D + h * D, t, quad);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dV0[h][t][i] = fmaf(v[t][i], opg[t][i], dV0[h][t][i]);
+            dg[e][i] = v[t][i] * v0[i];
+          }
         }
         if constexpr (BF16) {
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              FG.f[2 * (2 * k) + s][j] = (__bf16)dgam[8 * s + j];
-              FG.f[2 * (2 * k + 1) + s][j] = (__bf16)v[k][8 * s + j];
-            }
+          for (int j = 0; j < 8; ++j) {
+            FG.f[2 * m][j] = (__bf16)dg[j >> 2][j & 3];
+            FG.f[2 * m + 1][j] = (__bf16)v[2 * m + (j >> 2)][j & 3];
+          }
         } else {
-          FG.f[2 * k] = dgam;
-          FG.f[2 * k + 1] = v[k];
+          FG.f[4 * m] = dg[0]; FG.f[4 * m + 1] = dg[1];
+          FG.f[4 * m + 2] = v[2 * m]; FG.f[4 * m + 3] = v[2 * m + 1];
         }
       }
-      if (h + 1 < H) panel_gemm<2 * KB, KB, BF16, ST_GB>(dnh, FG, P, ring, gGB + h * PANEL_GG, pGB + (h + 1) * PANEL_GB, true, tid, lane);
-      else panel_gemm<2 * KB, KB, BF16, ST_DD>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, tid, lane);
+      if (h + 1 < H) panel_gemm<2 * KB, NT, BF16, ST_GB, BW>(dnh, FG, P, ring, gGB + h * PANEL_GG, pGB + (h + 1) * PANEL_GB, true, lane);
+      else panel_gemm<2 * KB, NT, BF16, ST_DD, BW>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, lane);
     }
 
     // ---------------- LN / gelu backward -> d a3 -> AF -> relu -> W1v -> d E_v -> d t_v -> d inv
@@ -394,89 +347,78 @@ __global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
     {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s1 += dnh[k][r]; s2 = fmaf(dnh[k][r], nh[k][r], s2); }
-      const float m1 = xhalf_sum(s1) * (1.0f / D), m2 = xhalf_sum(s2) * (1.0f / D);
+        for (int i = 0; i < 4; ++i) { s1 += dnh[t][i]; s2 = fmaf(dnh[t][i], nh[t][i], s2); }
+      const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dnh[k][r] = r1 * (dnh[k][r] - m1 - nh[k][r] * m2) * gelu_grad_f(a3[k][r]);   // d a3
+        for (int i = 0; i < 4; ++i) dnh[t][i] = r1 * (dnh[t][i] - m1 - nh[t][i] * m2) * gelu_grad_f(a3[t][i]);   // d a3
       make_frags<BF16, KB>(F, dnh);
-      f32x16 acc[KB];
+      f32x4 acc[NT];
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, gF, gV1, true, lane);                                 // d g1
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, gF, gV1, true, tid, lane);                                 // d g1
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = ((relu_mask >> (16 * k + r)) & 1ull) ? acc[k][r] : 0.f;          // d a2
+        for (int i = 0; i < 4; ++i) acc[t][i] = ((relu_mask >> (4 * t + i)) & 1u) ? acc[t][i] : 0.f;             // d a2
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, gV1, pQ1, true, tid, lane);                                // d E_v
-      f32x16 dT[TB];
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, gV1, pQ1, true, lane);                                // d E_v
+      f32x4 Ev[NT];
+      rff_embed<D, BF16>(Ev, inv, c_acv, lane, quad);                                                            // recomputed
+      f32x4 dT[TT];
       rff_embed_bwd<D>(dT, acc, Ev);
-      Frags<BF16, TB> FT;
-      make_frags<BF16, TB>(FT, dT);
-      f32x16 di[1];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) di[0][r] = 0.f;
-      gemm_stage<BF16, TB, 1>(di, FT, gcv, lane);
-      if (half == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
+      Frags<BF16, D / 64> FT;
+      make_frags<BF16, D / 64>(FT, dT);
+      f32x4 di[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      gemm_stage<BF16, D / 64, 1>(di, FT, gcv, lane);
+      if (quad == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
     }
     // ---------------- q-branch: recompute h1, then d u, d c, d h1 -> W1q -> d E_q -> d t_q -> d inv
     {
-      f32x16 E[KB];
-      rff_embed<D, BF16>(E, inv, c_acq, lane, half);
+      f32x4 E[NT];
+      rff_embed<D, BF16>(E, inv, c_acq, lane, quad);
       make_frags<BF16, KB>(F, E);
-      f32x16 acc[KB];
+      f32x4 acc[NT];
 #pragma unroll
-      for (int k = 0; k < KB; ++k) load_rowvec(acc[k], c_bq1, k, half);
+      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
       const bool more = ti + 1 < my_tiles;
-      panel_gemm<KB, KB, BF16, ST_DD>(acc, F, P, ring, pQ1, gQ1, true, tid, lane);                                // a1
+      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, pQ1, gQ1, true, lane);                                // a1
 #pragma unroll
-      for (int k = 0; k < KB; ++k) {
-        f32x16 dh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+      for (int t = 0; t < NT; ++t) {
+        f32x4 dh = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          f32x16 u;
-          load_rowvec(u, zv + h * D, k, half);
+          const f32x4 u = rowvec(zv + h * D, t, quad);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float h1 = fmaxf(acc[k][r], 0.f);
-            dU[h][k][r] = fmaf(dlogit[h], h1, dU[h][k][r]);
-            dh[r] = fmaf(dlogit[h], u[r], dh[r]);
+          for (int i = 0; i < 4; ++i) {
+            const float h1 = fmaxf(acc[t][i], 0.f);
+            dU[h][t][i] = fmaf(dlogit[h], h1, dU[h][t][i]);
+            dh[i] = fmaf(dlogit[h], u[i], dh[i]);
           }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = acc[k][r] > 0.f ? dh[r] : 0.f;                                   // d a1
+        for (int i = 0; i < 4; ++i) acc[t][i] = acc[t][i] > 0.f ? dh[i] : 0.f;                                   // d a1
       }
       Frags<BF16, KB> FA;
       make_frags<BF16, KB>(FA, acc);
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-      panel_gemm<KB, KB, BF16, ST_DD>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, tid, lane);             // d E_q
-      f32x16 dT[TB];
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, lane);             // d E_q
+      f32x4 dT[TT];
       rff_embed_bwd<D>(dT, acc, E);
-      Frags<BF16, TB> FT;
-      make_frags<BF16, TB>(FT, dT);
-      f32x16 di[1];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) di[0][r] = 0.f;
-      gemm_stage<BF16, TB, 1>(di, FT, gcq, lane);
-      if (half == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
+      Frags<BF16, D / 64> FT;
+      make_frags<BF16, D / 64>(FT, dT);
+      f32x4 di[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      gemm_stage<BF16, D / 64, 1>(di, FT, gcq, lane);
+      if (quad == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
     }
-    // ---------------- per-latent scalars (each column is counted once: lane half 0)
-    if (half == 0) {
+    // ---------------- per-latent scalars (each column is counted once: quad 0)
+    if (quad == 0) {
       float dwin = 0.f;
 #pragma unroll
       for (int h = 0; h < H; ++h) { dC[h] += dlogit[h]; dwin += dlogit[h]; }
@@ -484,20 +426,20 @@ __global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
     }
   }
 
-  // ---- fold the 32 columns and add this wave's share into the latent-table gradient
+  // ---- fold the 16 columns and add this wave's share into the latent-table gradient
   if (!active) return;   // no barrier follows
   float* drow = A.dlt + (size_t)bz * ltstride;
 #pragma unroll
   for (int h = 0; h < H; ++h)
 #pragma unroll
-    for (int k = 0; k < KB; ++k)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = dU[h][k][r], c = dV0[h][k][r];
+      for (int i = 0; i < 4; ++i) {
+        float a = dU[h][t][i], c = dV0[h][t][i];
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
         if (col == 0) {
-          const int f = 32 * k + RHO(r, 0) + 4 * half;
+          const int f = 16 * t + 4 * quad + i;
           atomicAdd(drow + enf_lt_off_u(H, D) + h * D + f, a);
           atomicAdd(drow + enf_lt_off_v0(H, D) + h * D + f, c);
         }
@@ -508,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
   sc[H] = dpose[0]; sc[H + 1] = dpose[1]; sc[H + 2] = dpose[2]; sc[H + 3] = dpose[3]; sc[H + 4] = dwc;
 #pragma unroll
   for (int i = 0; i < H + 5; ++i) {
-    float a = half == 0 ? sc[i] : 0.f;
+    float a = quad == 0 ? sc[i] : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     sc[i] = a;
@@ -532,8 +474,8 @@ static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
       return ENF_ELAUNCH;
     attr_set = true;
   }
-  dim3 grid((A.B * A.Z + 3) / 4, A.nsplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), SM::TOTAL, st, A);
+  dim3 grid((A.B * A.Z + BW - 1) / BW, A.nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(BTHREADS), SM::TOTAL, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
@@ -544,7 +486,7 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;
   A.dlt = dlt; A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
   // split the query tiles over grid.y until the chip (256 CUs) has ~2 workgroups per CU
-  const int wgs = (m.B * m.Z + 3) / 4, ntiles = (m.N + 31) / 32;
+  const int wgs = (m.B * m.Z + BW - 1) / BW, ntiles = (m.N + 15) / 16;
   int ns = 1;
   while (wgs * ns < 512 && ns * 2 <= ntiles) ns *= 2;
   A.nsplit = ns;

@@ -10,15 +10,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("bf16", [0, 1])
-@pytest.mark.parametrize("M,K", [(64, 64), (64, 128), (64, 32)])
+@pytest.mark.parametrize("M,K", [(64, 64), (64, 128), (64, 32), (16, 64)])
 def test_panel_gemm_exact(cuda, bf16, M, K):
     from enf_pde_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(M * 1000 + K + bf16)
     W = torch.randint(-4, 5, (K, M), generator=g).float().to(cuda)       # plain (in, out)
-    X = torch.randint(-4, 5, (K, 32), generator=g).float().to(cuda)      # (in, cols)
-    packed = torch.zeros((M // 32) * (K // 32) * (2048 if bf16 else 4096), dtype=torch.uint8, device=cuda)
-    Y = torch.zeros(M, 32, device=cuda)
+    X = torch.randint(-4, 5, (K, 16), generator=g).float().to(cuda)      # (in, cols)
+    packed = torch.zeros(M * K * (2 if bf16 else 4), dtype=torch.uint8, device=cuda)
+    Y = torch.zeros(M, 16, device=cuda)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     assert lib.enf_debug_pack(p(packed), p(W), M, K, bf16, st) == 0
