@@ -73,6 +73,29 @@ DEV void gemm_stage(f32x4* acc, const Frags<BF16, KB>& F, const char* lds, int l
   }
 }
 
+// FLIPPED product of ONE out-tile: the same panel fragments and the same activation fragments with
+// the MFMA operands swapped give (W^T X)^T, i.e. rows = this wave's columns n (register i <-> n =
+// 4*quad + i) and columns = the panel's out-features (lane & 15 <-> feature 16 mt + (lane&15)).
+// With the column index in registers, a sum over n (the gradient of a per-latent quantity) is a
+// lane-local sum over 4 registers instead of a cross-lane reduction.
+template <bool BF16, int KB>
+DEV void gemm_tile_flip(f32x4& acc, const Frags<BF16, KB>& F, const char* lds, int mt, int lane) {
+  if constexpr (BF16) {
+#pragma unroll
+    for (int blk = 0; blk < KB; ++blk) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + (((mt * KB + blk) * 64 + lane) << 4));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.f[blk], a, acc, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int tin = 0; tin < 2 * KB; ++tin) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(lds + (((mt * 2 * KB + tin) * 64 + lane) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[tin][i], a[i], acc, 0, 0, 0);
+    }
+  }
+}
+
 // per-row constant vector (bias, u, v0 ..) -> one tile in acc layout; `vec` is fp32 in LDS or
 // global; the address depends on the lane only through its quad, so the read is a broadcast.
 DEV f32x4 rowvec(const float* vec, int tile, int quad) {
@@ -167,6 +190,30 @@ DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, ch
     if (sp + 1 < C::SPP) stage_issue<C::STAGE, NW>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
     else if (next != NO_STAGE) stage_issue<NEXT_BYTES, NW>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
     if (active) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane);
+    stage_wait();
+    __syncthreads();
+    P.cur ^= 1;
+  }
+}
+
+// panel_gemm that additionally hands every out-tile's FLIPPED product to `flip(tile, acc)`
+// (acc starts at flip_init(tile)); TRANS = false skips the transposed product.
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW, bool TRANS, typename InitFn, typename FlipFn>
+DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel,
+                         unsigned next, int lane, InitFn&& flip_init, FlipFn&& flip) {
+  using C = PanelCfg<KBIN, MTOUT, BF16>;
+#pragma unroll
+  for (int sp = 0; sp < C::SPP; ++sp) {
+    if (sp + 1 < C::SPP) stage_issue<C::STAGE, NW>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    else if (next != NO_STAGE) stage_issue<NEXT_BYTES, NW>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    const char* slot = ring + P.cur * STAGE_MAX;
+    if constexpr (TRANS) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, slot, lane);
+#pragma unroll
+    for (int mt = 0; mt < C::MTS; ++mt) {
+      f32x4 af = flip_init(sp * C::MTS + mt);
+      gemm_tile_flip<BF16, KBIN>(af, F, slot, mt, lane);
+      flip(sp * C::MTS + mt, af);
+    }
     stage_wait();
     __syncthreads();
     P.cur ^= 1;

@@ -12,8 +12,10 @@
 // Per tile (H heads):  q-forward (logits) -> v-forward to n^ -> per head {gamma/beta, mixer
 // forward, mixer backward, FiLM backward, gamma/beta backward} -> LN/gelu/relu backward to the
 // value RFF -> q-branch recompute + backward -> invariant Jacobian.  608 MFMAs (16x16x32 bf16)
-// per tile at D=128, H=2 against 288 in the forward.  4 waves per workgroup (one per SIMD): the
-// per-lane partial sums (d u, d v0) need the 512-register budget.
+// per tile at D=128, H=2 against 288 in the forward.  The two big per-latent sums
+// (d u = sum_n dlogit h1, d v0 = sum_n dv (1+gamma)) are taken on FLIPPED products (enf_device.h:
+// gemm_tile_flip -- same panels, MFMA operands swapped) whose rows are the queries, so they cost 4
+// FMAs per 16x16 tile and 32 accumulator registers instead of 128; +160 MFMAs per tile.
 #include <hip/hip_runtime.h>
 #include "enf_layout.h"
 #include "enf_device.h"
@@ -27,9 +29,6 @@ struct PairBwdArgs {
   int B, N, Z, dx, inv, use_window, nsplit;
 };
 
-constexpr int BW = 4;                 // waves per workgroup in this kernel
-constexpr int BTHREADS = 64 * BW;
-
 template <int D, int H, bool BF16> struct PairBwdSmem {
   static constexpr int RING = 0;
   static constexpr int CONSTS = RING + 2 * STAGE_MAX;
@@ -37,8 +36,8 @@ template <int D, int H, bool BF16> struct PairBwdSmem {
   static constexpr int N_CONST = 4 * D + 2 * H * D + 4 * D;
   static constexpr int GC = CONSTS + 4 * N_CONST;                          // gcq | gcv panels
   static constexpr int GC_BYTES = PanelCfg<D / 64, 1, BF16>::BYTES;
-  static constexpr int ZVEC = GC + 2 * GC_BYTES;                           // BW waves x 2HD floats
-  static constexpr int TOTAL = ZVEC + 4 * BW * 2 * H * D;
+  static constexpr int ZVEC = GC + 2 * GC_BYTES;                           // NWAVES x 2HD floats
+  static constexpr int TOTAL = ZVEC + 4 * NWAVES * 2 * H * D;
 };
 
 // d t = d E_sin * E_cos - d E_cos * E_sin   (the 2 pi is folded into the gc panel)
@@ -48,6 +47,42 @@ template <int D> DEV void rff_embed_bwd(f32x4 (&dT)[D / 32], const f32x4 (&dE)[D
   for (int m = 0; m < TT; ++m)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dT[m][i] = dE[m][i] * E[TT + m][i] - dE[TT + m][i] * E[m][i];
+}
+
+// gamma/beta panel of one head: transposed product -> v = v0 (1+gamma) + beta (as gb_panel), and the
+// FLIPPED product of the gamma tiles -> opgf[d-tile] = 1 + gamma with rows = queries (for d v0).
+template <int D, bool BF16, int NEXT_BYTES>
+DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF16, D / 32>& F, Pipe& P, char* ring,
+                       unsigned panel, unsigned next, const float* bias, const float* v0vec, int lane, int col, int quad) {
+  using C = typename PairCfg<D, BF16>::GB;
+  constexpr int KB = D / 32, MTS = C::MTS;
+#pragma unroll
+  for (int sp = 0; sp < C::SPP; ++sp) {
+    if (sp + 1 < C::SPP) stage_issue<C::STAGE>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    const char* slot = ring + P.cur * STAGE_MAX;
+    f32x4 t[MTS];
+#pragma unroll
+    for (int j = 0; j < MTS; ++j) t[j] = rowvec(bias, sp * MTS + j, quad);
+    gemm_stage<BF16, KB, MTS>(t, F, slot, lane);
+#pragma unroll
+    for (int g = 0; g < MTS / 4; ++g) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int tile = 2 * (sp * (MTS / 4) + g) + e;
+        const f32x4 v0 = rowvec(v0vec, tile, quad);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[tile][i] = fmaf(v0[i], 1.0f + t[4 * g + e][i], t[4 * g + 2 + e][i]);
+        const float bc = 1.0f + bias[16 * (sp * MTS + 4 * g + e) + col];      // per-column bias of the flipped tile
+        f32x4 af = {bc, bc, bc, bc};
+        gemm_tile_flip<BF16, KB>(af, F, slot, 4 * g + e, lane);
+        opgf[tile] = af;
+      }
+    }
+    stage_wait();
+    __syncthreads();
+    P.cur ^= 1;
+  }
 }
 
 // Jacobian of (invariant, window) w.r.t. the latent pose row and the window coefficient.
@@ -121,13 +156,14 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
 }
 
 template <int D, int H, bool BF16>
-__global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A) {
+__global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A) {
   using Cfg = PairCfg<D, BF16>;
   using SM = PairBwdSmem<D, H, BF16>;
   constexpr int KB = Cfg::KB, NT = Cfg::NT, TT = D / 32;
   constexpr int ST_DD = Cfg::DD::STAGE, ST_GB = Cfg::GB::STAGE, PANEL_GB = Cfg::GB::BYTES;
   using GG = PanelCfg<2 * KB, NT, BF16>;              // one head's d n^ += AGB_h [dgamma; dbeta]
   constexpr int ST_GG = GG::STAGE, PANEL_GG = GG::BYTES;
+  constexpr int NW = NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem + SM::RING;
   float* cst = reinterpret_cast<float*>(smem + SM::CONSTS);
@@ -140,16 +176,16 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
-  const int bz = blockIdx.x * BW + wave;
+  const int bz = blockIdx.x * NW + wave;
   const bool active = bz < A.B * A.Z;
   const int bzc = active ? bz : A.B * A.Z - 1;
   const int b = bzc / A.Z;
   const int split = blockIdx.y;
 
-  for (int i = tid; i < D; i += BTHREADS) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
-  for (int i = tid; i < 2 * H * D; i += BTHREADS) c_bgb[i] = G(A.L.bgb)[i];
-  for (int i = tid; i < 2 * D; i += BTHREADS) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
-  for (int i = tid; i < SM::GC_BYTES / 4; i += BTHREADS) {
+  for (int i = tid; i < D; i += NTHREADS) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
+  for (int i = tid; i < 2 * H * D; i += NTHREADS) c_bgb[i] = G(A.L.bgb)[i];
+  for (int i = tid; i < 2 * D; i += NTHREADS) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
+  for (int i = tid; i < SM::GC_BYTES / 4; i += NTHREADS) {
     reinterpret_cast<float*>(gcq)[i] = G(A.L.gcq)[i];
     reinterpret_cast<float*>(gcv)[i] = G(A.L.gcv)[i];
   }
@@ -170,16 +206,16 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
 
   Pipe P;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
-  first_stage<ST_DD, BW>(P, ring, pQ1, wave, lane);
+  first_stage<ST_DD>(P, ring, pQ1, wave, lane);
 
-  // per-lane partial sums over this wave's queries
-  f32x4 dU[H][NT], dV0[H][NT];
-  float dC[H], dpose[4] = {0.f, 0.f, 0.f, 0.f}, dwc = 0.f;
+  // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature
+  // 16 t + col, summed over the queries n = 4 quad + i of every tile (flipped products).
+  float dU[H][NT], dV0[H][NT], dC[H], dpose[4] = {0.f, 0.f, 0.f, 0.f}, dwc = 0.f;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     dC[h] = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { dU[h][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dV0[h][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < NT; ++t) { dU[h][t] = 0.f; dV0[h][t] = 0.f; }
   }
 
   const int ntiles = (A.N + 15) / 16;
@@ -202,7 +238,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
-      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, pQ1, pV1, true, lane);
+      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pQ1, pV1, true, lane);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float s = 0.f;
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bv1, t, quad);
-      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, pV1, pF, true, lane);
+      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pV1, pF, true, lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -237,7 +273,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) a3[t] = rowvec(c_bf, t, quad);
-      panel_gemm<KB, NT, BF16, ST_GB, BW>(a3, F, P, ring, pF, pGB, true, lane);
+      panel_gemm<KB, NT, BF16, ST_GB>(a3, F, P, ring, pF, pGB, true, lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -255,16 +291,16 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
 
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      f32x4 v[NT], opg[NT];
-      gb_panel<D, BF16, ST_DD, true, BW>(v, opg, F, P, ring, pGB + h * PANEL_GB, pM, true, c_bgb + 2 * h * D,
-                                         zv + H * D + h * D, lane, quad);
+      f32x4 v[NT], opgf[NT];
+      gb_panel_flip<D, BF16, ST_DD>(v, opgf, F, P, ring, pGB + h * PANEL_GB, pM, c_bgb + 2 * h * D, zv + H * D + h * D,
+                                    lane, col, quad);
       f32x4 a5[NT];
       {
         Frags<BF16, KB> FV;
         make_frags<BF16, KB>(FV, v);
 #pragma unroll
         for (int t = 0; t < NT; ++t) a5[t] = rowvec(c_bm, t, quad);
-        panel_gemm<KB, NT, BF16, ST_DD, BW>(a5, FV, P, ring, pM, gM, true, lane);
+        panel_gemm<KB, NT, BF16, ST_DD>(a5, FV, P, ring, pM, gM, true, lane);
       }
       // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
       float mu2, r2;
@@ -303,15 +339,20 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * gelu_grad_f(a5[t][i]);   // d a5
-      // d v = AM d a5
+      // d v = AM d a5 (transposed, feeds d gamma / d beta) and its flipped twin:
+      // d v0[d] += sum_n dv[n][d] (1 + gamma[n][d])
       {
         Frags<BF16, KB> FA;
         make_frags<BF16, KB>(FA, dy);
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        panel_gemm<KB, NT, BF16, ST_GG, BW>(v, FA, P, ring, gM, gGB + h * PANEL_GG, true, lane);               // v <- d v
+        panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true>(
+            v, FA, P, ring, gM, gGB + h * PANEL_GG, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
+            [&](int mt, const f32x4& af) {
+              dV0[h][mt] += af[0] * opgf[mt][0] + af[1] * opgf[mt][1] + af[2] * opgf[mt][2] + af[3] * opgf[mt][3];
+            });                                                                                               // v <- d v
       }
-      // FiLM backward: d v0 += d v (1+gamma); d gamma = d v * v0; d beta = d v.
+      // FiLM backward: d gamma = d v * v0; d beta = d v.
       // B operand of the [g g b b]-ordered panel: block 2m = d gamma (tiles 2m, 2m+1), block 2m+1 = d beta
       Frags<BF16, 2 * KB> FG;
 #pragma unroll
@@ -319,13 +360,9 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
         f32x4 dg[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int t = 2 * m + e;
-          const f32x4 v0 = rowvec(zv + H * D + h * D, t, quad);
+          const f32x4 v0 = rowvec(zv + H * D + h * D, 2 * m + e, quad);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            dV0[h][t][i] = fmaf(v[t][i], opg[t][i], dV0[h][t][i]);
-            dg[e][i] = v[t][i] * v0[i];
-          }
+          for (int i = 0; i < 4; ++i) dg[e][i] = v[2 * m + e][i] * v0[i];
         }
         if constexpr (BF16) {
 #pragma unroll
@@ -338,8 +375,8 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
           FG.f[4 * m + 2] = v[2 * m]; FG.f[4 * m + 3] = v[2 * m + 1];
         }
       }
-      if (h + 1 < H) panel_gemm<2 * KB, NT, BF16, ST_GB, BW>(dnh, FG, P, ring, gGB + h * PANEL_GG, pGB + (h + 1) * PANEL_GB, true, lane);
-      else panel_gemm<2 * KB, NT, BF16, ST_DD, BW>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, lane);
+      if (h + 1 < H) panel_gemm<2 * KB, NT, BF16, ST_GB>(dnh, FG, P, ring, gGB + h * PANEL_GG, pGB + (h + 1) * PANEL_GB, true, lane);
+      else panel_gemm<2 * KB, NT, BF16, ST_DD>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, lane);
     }
 
     // ---------------- LN / gelu backward -> d a3 -> AF -> relu -> W1v -> d E_v -> d t_v -> d inv
@@ -359,7 +396,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, gF, gV1, true, lane);                                 // d g1
+      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, gF, gV1, true, lane);                                     // d g1
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -367,7 +404,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, gV1, pQ1, true, lane);                                // d E_v
+      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, gV1, pQ1, true, lane);                                    // d E_v
       f32x4 Ev[NT];
       rff_embed<D, BF16>(Ev, inv, c_acv, lane, quad);                                                            // recomputed
       f32x4 dT[TT];
@@ -378,7 +415,8 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       gemm_stage<BF16, D / 64, 1>(di, FT, gcv, lane);
       if (quad == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
     }
-    // ---------------- q-branch: recompute h1, then d u, d c, d h1 -> W1q -> d E_q -> d t_q -> d inv
+    // ---------------- q-branch: recompute a1 (transposed, for the relu mask of d h1) and its flipped
+    // twin h1f (rows = queries) for d u[f] += sum_n dlogit[n] h1f[n][f]
     {
       f32x4 E[NT];
       rff_embed<D, BF16>(E, inv, c_acq, lane, quad);
@@ -386,8 +424,21 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
+      float dl[H][4];                     // dlogit of the 4 queries this lane's flipped rows hold
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dl[h][i] = __shfl(dlogit[h], (quad << 4) | (4 * quad + i), 64);
       const bool more = ti + 1 < my_tiles;
-      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, F, P, ring, pQ1, gQ1, true, lane);                                // a1
+      panel_gemm_flip<KB, NT, BF16, ST_DD, NW, true>(
+          acc, F, P, ring, pQ1, gQ1, lane,
+          [&](int mt) { const float bc = c_bq1[16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
+          [&](int mt, const f32x4& af) {
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+              dU[h][mt] += dl[h][0] * fmaxf(af[0], 0.f) + dl[h][1] * fmaxf(af[1], 0.f) + dl[h][2] * fmaxf(af[2], 0.f) +
+                           dl[h][3] * fmaxf(af[3], 0.f);
+          });                                                                                                    // a1
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         f32x4 dh = {0.f, 0.f, 0.f, 0.f};
@@ -395,11 +446,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int h = 0; h < H; ++h) {
           const f32x4 u = rowvec(zv + h * D, t, quad);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float h1 = fmaxf(acc[t][i], 0.f);
-            dU[h][t][i] = fmaf(dlogit[h], h1, dU[h][t][i]);
-            dh[i] = fmaf(dlogit[h], u[i], dh[i]);
-          }
+          for (int i = 0; i < 4; ++i) dh[i] = fmaf(dlogit[h], u[i], dh[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = acc[t][i] > 0.f ? dh[i] : 0.f;                                   // d a1
@@ -408,7 +455,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(FA, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      panel_gemm<KB, NT, BF16, ST_DD, BW>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, lane);             // d E_q
+      panel_gemm<KB, NT, BF16, ST_DD>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, lane);                 // d E_q
       f32x4 dT[TT];
       rff_embed_bwd<D>(dT, acc, E);
       Frags<BF16, D / 64> FT;
@@ -426,24 +473,19 @@ __global__ __launch_bounds__(BTHREADS, 1) void enf_pair_bwd_kernel(PairBwdArgs A
     }
   }
 
-  // ---- fold the 16 columns and add this wave's share into the latent-table gradient
+  // ---- fold the partial sums and add this wave's share into the latent-table gradient
   if (!active) return;   // no barrier follows
   float* drow = A.dlt + (size_t)bz * ltstride;
 #pragma unroll
   for (int h = 0; h < H; ++h)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float a = dU[h][t][i], c = dV0[h][t][i];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
-        if (col == 0) {
-          const int f = 16 * t + 4 * quad + i;
-          atomicAdd(drow + enf_lt_off_u(H, D) + h * D + f, a);
-          atomicAdd(drow + enf_lt_off_v0(H, D) + h * D + f, c);
-        }
+    for (int t = 0; t < NT; ++t) {
+      const float a = xquad_sum(dU[h][t]), c = xquad_sum(dV0[h][t]);
+      if (quad == 0) {
+        atomicAdd(drow + enf_lt_off_u(H, D) + h * D + 16 * t + col, a);
+        atomicAdd(drow + enf_lt_off_v0(H, D) + h * D + 16 * t + col, c);
       }
+    }
   float sc[H + 5];
 #pragma unroll
   for (int h = 0; h < H; ++h) sc[h] = dC[h];
@@ -474,8 +516,8 @@ static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
       return ENF_ELAUNCH;
     attr_set = true;
   }
-  dim3 grid((A.B * A.Z + BW - 1) / BW, A.nsplit);
-  hipLaunchKernelGGL(kern, grid, dim3(BTHREADS), SM::TOTAL, st, A);
+  dim3 grid((A.B * A.Z + NWAVES - 1) / NWAVES, A.nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SM::TOTAL, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
@@ -485,10 +527,10 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
   PairBwdArgs A;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;
   A.dlt = dlt; A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
-  // split the query tiles over grid.y until the chip (256 CUs) has ~2 workgroups per CU
-  const int wgs = (m.B * m.Z + BW - 1) / BW, ntiles = (m.N + 15) / 16;
+  // one workgroup per CU is resident (LDS): split the query tiles over grid.y until all 256 CUs have one
+  const int wgs = (m.B * m.Z + NWAVES - 1) / NWAVES, ntiles = (m.N + 15) / 16;
   int ns = 1;
-  while (wgs * ns < 512 && ns * 2 <= ntiles) ns *= 2;
+  while (wgs * ns < 256 && ns * 2 <= ntiles) ns *= 2;
   A.nsplit = ns;
 #define ENF_CASE(DD, HH)                                                                   \
   if (m.D == DD && m.H == HH) return m.bf16 ? launch_pair_bwd<DD, HH, true>(A, st) : launch_pair_bwd<DD, HH, false>(A, st);
