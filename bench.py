@@ -177,7 +177,8 @@ def main():
     rank, world, local_rank = init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decoder has no CPU path")
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    # one rank per GPU (the driver's launch); ENF_DIST_BACKEND=gloo lets several ranks share one GPU in rehearsals
+    device = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(device)
 
     nef, params, lat0, lrs, masks = build(device, args.precision)
@@ -198,7 +199,8 @@ def main():
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        on_gpu = torch.distributed.get_backend() == "nccl"
+        t = torch.tensor([dt], device=device if on_gpu else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -1,6 +1,6 @@
 """Dev probe (GPU box): per-call timings of forward / backward at the bench shapes."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Dev probe (GPU box): error vs oracle and forward timings at the BASELINE config-2 shape."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import enf_ref_np as R
 from tests.helpers import make_cfg, make_inputs, build_nef
 
