@@ -228,20 +228,17 @@ template <int BYTES, int NW = NWAVES> DEV void first_stage(Pipe& P, char* ring, 
   __syncthreads();
 }
 
-// LayerNorm statistics over the NT*16 features of this lane's column (biased variance, eps 1e-6)
+// LayerNorm statistics over the NT*16 features of this lane's column: biased variance, eps 1e-6,
+// one pass (E[x^2] - E[x]^2, flax.linen.LayerNorm's default use_fast_variance=True)
 template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd) {
-  float s = 0.f;
+  float s = 0.f, q = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s += X[t][i];
+    for (int i = 0; i < 4; ++i) { s += X[t][i]; q = fmaf(X[t][i], X[t][i], q); }
   mu = xquad_sum(s) * (1.0f / (16 * NT));
-  float q = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const float d = X[t][i] - mu; q = fmaf(d, d, q); }
-  rstd = rsqrtf(xquad_sum(q) * (1.0f / (16 * NT)) + 1e-6f);
+  const float ex2 = xquad_sum(q) * (1.0f / (16 * NT));
+  rstd = rsqrtf(fmaxf(ex2 - mu * mu, 0.f) + 1e-6f);
 }
 
 // ------------------------------------------------------------------ invariants + window

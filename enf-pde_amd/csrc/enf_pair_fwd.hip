@@ -143,10 +143,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
         for (int i = 0; i < 4; ++i) acc[t][i] = gelu_f(acc[t][i]);
       float mu, rstd;
       ln_stats<NT>(acc, mu, rstd);
+      const float nmr = -mu * rstd;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = (acc[t][i] - mu) * rstd;
+        for (int i = 0; i < 4; ++i) acc[t][i] = fmaf(acc[t][i], rstd, nmr);
       make_frags<BF16, KB>(F, acc);   // F = normalised f, shared by all heads' gamma/beta panels
     }
 #pragma unroll
