@@ -11,7 +11,7 @@ int enf_launch_prologue_bwd(const EnfDims&, const EnfLayout&, const char*, const
 int enf_launch_pair_fwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, float*, float*,
                         hipStream_t);
 int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, const float*,
-                        const float*, const float*, float*, hipStream_t);
+                        const float*, const float*, float*, void* const*, hipStream_t);
 int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
                     int, hipStream_t);
 }
@@ -115,7 +115,43 @@ extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_
   if ((rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
   if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, st))) return rc;
   if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
-  if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), st))) return rc;
+  if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr, st))) return rc;
   if ((rc = enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st))) return rc;
   return ENF_OK;
+}
+
+extern "C" int enf_lt_layout(const EnfDesc* d, int* stride, int* off_u, int* off_v0, int* off_pose, int* off_wcoef, int* off_c) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (stride) *stride = enf_lt_stride(d->H, d->D);
+  if (off_u) *off_u = enf_lt_off_u(d->H, d->D);
+  if (off_v0) *off_v0 = enf_lt_off_v0(d->H, d->D);
+  if (off_pose) *off_pose = enf_lt_off_pose(d->H, d->D);
+  if (off_wcoef) *off_wcoef = enf_lt_off_wcoef(d->H, d->D);
+  if (off_c) *off_c = enf_lt_off_c(d->H, d->D);
+  return ENF_OK;
+}
+
+extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                                float* ybar, float* lse, void* stream) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (!x || !lt || !packed || !ybar || !lse) return ENF_EINVAL;
+  const EnfDims m = enf_dims(d);
+  return enf_launch_pair_fwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, ybar, lse, (hipStream_t)stream);
+}
+
+extern "C" int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                                 const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
+                                 void* stream) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (!x || !lt || !packed || !lse || !dybar || !delta || !dlt) return ENF_EINVAL;
+  const EnfDims m = enf_dims(d);
+  if (store)
+    for (int i = 0; i < ENF_NUM_STORE(m.H); ++i)
+      if (!store[i]) return ENF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dlt, 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
+  return enf_launch_pair_bwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, lse, dybar, delta, dlt, store, st);
 }

@@ -105,6 +105,63 @@ static inline int pack_panel(hipStream_t st, char* blob, size_t off, const float
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
+// Panels of the per-pair chain (forward: A[out][in] = W[in][out]; backward: A[in][out] = W[in][out], dX = W dY)
+// from plain (in, out) matrices; `agb` is D x 2HD in the [g g b b] interleaved column order.
+static int pack_pair_panels(hipStream_t st, char* blob, const EnfLayout& L, const EnfDims& m, const float* aq1,
+                            const float* av1, const float* af, const float* agb, const float* am, const float* coefq,
+                            const float* coefv) {
+  const int D = m.D, H = m.H, HD = m.HD, I = m.I, bf = m.bf16;
+  int rc;
+  {
+    const int tot = (D / 32) * 64;
+    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<float*>(blob + L.acq), coefq, I, D / 2);
+    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<float*>(blob + L.acv), coefv, I, D / 2);
+    if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
+  }
+  if ((rc = pack_panel(st, blob, L.aq1, aq1, D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.av1, av1, D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.af, af, D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.agb, agb, 2 * HD, 2 * HD, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.am, am, D, D, D, 0, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gq1, aq1, D, D, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gv1, av1, D, D, D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gf, af, D, D, D, 1, bf))) return rc;
+  for (int h = 0; h < H; ++h)   // one K-slice (that head's [g g b b ..] 2D columns) per head
+    if ((rc = pack_panel(st, blob, L.ggb + (size_t)h * enf_panel_bytes(D, 2 * D, bf), agb + h * 2 * D, 2 * HD, D, 2 * D, 1, bf))) return rc;
+  if ((rc = pack_panel(st, blob, L.gm, am, D, D, D, 1, bf))) return rc;
+  // d inv[c] = sum_t 2 pi coeff[c][t] d t[t]  (RFF:92)
+  if ((rc = pack_panel(st, blob, L.gcq, coefq, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
+  if ((rc = pack_panel(st, blob, L.gcv, coefv, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
+  return ENF_OK;
+}
+
+// Pack ONLY what the pair kernels (enf_pair_forward / enf_pair_backward) read, from the "effective"
+// per-pair parameters (ENF_P_* order, include/enf_hip.h): used by the training path, where folds,
+// latent prologue and tail run as differentiable host-framework ops around the HIP pair kernels.
+extern "C" int enf_pack_pair(const EnfDesc* d, const float* const* T, void* packed, void* stream) {
+  if (!d || !T || !packed) return ENF_EINVAL;
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  for (int i = 0; i < ENF_NUM_PAIR_TENSORS; ++i)
+    if (!T[i]) return ENF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const EnfDims m = enf_dims(d);
+  const EnfLayout L = enf_layout(m);
+  char* blob = (char*)packed;
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
+  const int D = m.D, H = m.H, HD = m.HD;
+  const size_t f = sizeof(float);
+  auto cp = [&](size_t off, const float* src, size_t n) {
+    return hipMemcpyAsync(blob + off, src, n * f, hipMemcpyDeviceToDevice, st);
+  };
+  CK(cp(L.bq1, T[ENF_P_BQ1], D)); CK(cp(L.bv1, T[ENF_P_BV1], D)); CK(cp(L.bf, T[ENF_P_BF], D)); CK(cp(L.bm, T[ENF_P_BM], D));
+  hipLaunchKernelGGL(reorder_gb_kernel, dim3((2 * HD + 127) / 128, 1), dim3(128), 0, st, F(L.bgb), T[ENF_P_BGB], (const float*)nullptr, 1, H, D);
+  hipLaunchKernelGGL(reorder_gb_kernel, dim3((2 * HD + 127) / 128, D), dim3(128), 0, st, F(L.p_agb), T[ENF_P_AGB], (const float*)nullptr, D, H, D);
+  if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
+  return pack_pair_panels(st, blob, L, m, T[ENF_P_AQ1], T[ENF_P_AV1], T[ENF_P_AF], F(L.p_agb), T[ENF_P_AM], T[ENF_P_COEFQ],
+                          T[ENF_P_COEFV]);
+}
+
 // test-only: pack a plain fp32 (K x M row-major, W[k][m]) matrix as the A operand A[m][k] = W[k][m]
 extern "C" int enf_debug_pack(void* dst, const float* W, int M, int K, int bf16, void* stream) {
   const size_t total = (size_t)M * K;
@@ -124,7 +181,7 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
   const EnfLayout L = enf_layout(m);
   char* blob = (char*)packed;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
-  const int D = m.D, H = m.H, HD = m.HD, C = m.C, O = m.O, I = m.I, OP = 32 * m.OB;
+  const int D = m.D, H = m.H, HD = m.HD, C = m.C, O = m.O, OP = 32 * m.OB;
   const size_t f = sizeof(float);
   const float scale = 1.0f / sqrtf((float)D);  // ECA:59
   auto cp = [&](size_t off, const float* src, size_t n) {
@@ -138,12 +195,6 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
   for (int h = 0; h < H; ++h) {
     if ((rc = mm(st, F(L.mu) + (size_t)h * D * D, D, T[ENF_W_RQ_W2], D, T[ENF_W_Q_W] + h * D, HD, D, D, D, scale, nullptr, 0))) return rc;
     if ((rc = mm(st, F(L.cvec) + (size_t)h * D, D, T[ENF_W_RQ_B2], D, T[ENF_W_Q_W] + h * D, HD, 1, D, D, scale, T[ENF_W_Q_B] + h * D, 0))) return rc;
-  }
-  // ---- RFF coefficient fragments
-  {
-    const int tot = (D / 32) * 64;
-    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, F(L.acq), T[ENF_W_RQ_COEF], I, D / 2);
-    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, F(L.acv), T[ENF_W_RV_COEF], I, D / 2);
   }
   // ---- per-pair biases
   CK(cp(L.bq1, T[ENF_W_RQ_B1], D)); CK(cp(L.bv1, T[ENF_W_RV_B1], D)); CK(cp(L.bm, T[ENF_W_MX_B0], D));
@@ -168,28 +219,16 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
   hipLaunchKernelGGL(padcopy_kernel, dim3((OP + 127) / 128, 1), dim3(128), 0, st, F(L.bO4), T[ENF_W_O4_B], 1, O, OP);
   hipLaunchKernelGGL(padcopy_kernel, dim3((OP + 127) / 128, D), dim3(128), 0, st, F(L.p_o4), T[ENF_W_O4_W], D, O, OP);
   if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
-  // ---- forward panels: A[out][in] = W[in][out]
+  // ---- panels
   const int bf = m.bf16;
-  if ((rc = pack_panel(st, blob, L.aq1, T[ENF_W_RQ_W1], D, D, D, 0, bf))) return rc;
-  if ((rc = pack_panel(st, blob, L.av1, T[ENF_W_RV_W1], D, D, D, 0, bf))) return rc;
-  if ((rc = pack_panel(st, blob, L.af, F(L.p_af), D, D, D, 0, bf))) return rc;
-  if ((rc = pack_panel(st, blob, L.agb, F(L.p_agb), 2 * HD, 2 * HD, D, 0, bf))) return rc;
-  if ((rc = pack_panel(st, blob, L.am, T[ENF_W_MX_W0], D, D, D, 0, bf))) return rc;
+  if ((rc = pack_pair_panels(st, blob, L, m, T[ENF_W_RQ_W1], T[ENF_W_RV_W1], F(L.p_af), F(L.p_agb), T[ENF_W_MX_W0],
+                             T[ENF_W_RQ_COEF], T[ENF_W_RV_COEF]))) return rc;
+  // tail, forward: A[out][in] = W[in][out]; backward: A[in][out] = W[in][out]  (dX = W dY)
   if ((rc = pack_panel(st, blob, L.atb, F(L.p_wb), HD, HD, HD, 0, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.atf1, F(L.p_wf1), HD, HD, HD, 0, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.ato0, T[ENF_W_O0_W], D, D, HD, 0, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.ato2, T[ENF_W_O2_W], D, D, D, 0, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.ato4, F(L.p_o4), OP, OP, D, 0, bf))) return rc;
-  // ---- backward panels: A[in][out] = W[in][out]   (dX = W dY)
-  if ((rc = pack_panel(st, blob, L.gq1, T[ENF_W_RQ_W1], D, D, D, 1, bf))) return rc;
-  if ((rc = pack_panel(st, blob, L.gv1, T[ENF_W_RV_W1], D, D, D, 1, bf))) return rc;
-  if ((rc = pack_panel(st, blob, L.gf, F(L.p_af), D, D, D, 1, bf))) return rc;
-  for (int h = 0; h < H; ++h)   // one K-slice (that head's [g b g b ..] 2D columns) per head
-    if ((rc = pack_panel(st, blob, L.ggb + (size_t)h * enf_panel_bytes(D, 2 * D, bf), F(L.p_agb) + h * 2 * D, 2 * HD, D, 2 * D, 1, bf))) return rc;
-  // d inv[c] = sum_t 2 pi coeff[c][t] d t[t]  (RFF:92)
-  if ((rc = pack_panel(st, blob, L.gcq, T[ENF_W_RQ_COEF], D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
-  if ((rc = pack_panel(st, blob, L.gcv, T[ENF_W_RV_COEF], D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
-  if ((rc = pack_panel(st, blob, L.gm, T[ENF_W_MX_W0], D, D, D, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gtb, F(L.p_wb), HD, HD, HD, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gtf1, F(L.p_wf1), HD, HD, HD, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gto0, T[ENF_W_O0_W], D, HD, D, 1, bf))) return rc;

@@ -26,8 +26,29 @@ struct PairBwdArgs {
   const float* lt; const char* blob; EnfLayout L;
   const float* lse; const float* dybar; const float* delta;
   float* dlt;
+  void* store[ENF_NUM_STORE(2)];        // ENF_S_* buffers (STORE instantiation only)
   int B, N, Z, dx, inv, use_window, nsplit;
 };
+
+// one row of a materialised activation / delta = this lane's share of a fragment set
+template <bool BF16, int KB>
+DEV void store_frags(void* base, size_t row, int D, const Frags<BF16, KB>& F, int quad) {
+  if constexpr (BF16) {
+    __bf16* p = reinterpret_cast<__bf16*>(base) + row * D;
+#pragma unroll
+    for (int blk = 0; blk < KB; ++blk) {
+      bf16x4 lo, hi;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { lo[i] = F.f[blk][i]; hi[i] = F.f[blk][4 + i]; }
+      *reinterpret_cast<bf16x4*>(p + 32 * blk + 4 * quad) = lo;
+      *reinterpret_cast<bf16x4*>(p + 32 * blk + 16 + 4 * quad) = hi;
+    }
+  } else {
+    float* p = reinterpret_cast<float*>(base) + row * D;
+#pragma unroll
+    for (int t = 0; t < 2 * KB; ++t) *reinterpret_cast<f32x4*>(p + 16 * t + 4 * quad) = F.f[t];
+  }
+}
 
 template <int D, int H, bool BF16> struct PairBwdSmem {
   static constexpr int RING = 0;
@@ -155,7 +176,7 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
   }
 }
 
-template <int D, int H, bool BF16>
+template <int D, int H, bool BF16, bool STORE>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A) {
   using Cfg = PairCfg<D, BF16>;
   using SM = PairBwdSmem<D, H, BF16>;
@@ -228,6 +249,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
     float inv[4], win;
     pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win);
+    const size_t srow = (size_t)bzc * A.N + n;        // row of the materialised activations (STORE)
+    const bool swrite = STORE && nvalid && active;
 
     // ---------------- q-forward: logits -> attention probabilities
     float att[H], dlogit[H];
@@ -260,6 +283,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
       make_frags<BF16, KB>(F, acc);
+      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EV], srow, D, F, quad);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bv1, t, quad);
       panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pV1, pF, true, lane);
@@ -271,6 +295,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           acc[t][i] = fmaxf(acc[t][i], 0.f);
         }
       make_frags<BF16, KB>(F, acc);
+      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
 #pragma unroll
       for (int t = 0; t < NT; ++t) a3[t] = rowvec(c_bf, t, quad);
       panel_gemm<KB, NT, BF16, ST_GB>(a3, F, P, ring, pF, pGB, true, lane);
@@ -284,6 +309,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) nh[t][i] = (nh[t][i] - mu1) * r1;
       make_frags<BF16, KB>(F, nh);
+      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_NH], srow, D, F, quad);
     }
     f32x4 dnh[NT];                       // d n^ accumulated over heads
 #pragma unroll
@@ -298,6 +324,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       {
         Frags<BF16, KB> FV;
         make_frags<BF16, KB>(FV, v);
+        if (swrite) store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h], srow, D, FV, quad);
 #pragma unroll
         for (int t = 0; t < NT; ++t) a5[t] = rowvec(c_bm, t, quad);
         panel_gemm<KB, NT, BF16, ST_DD>(a5, FV, P, ring, pM, gM, true, lane);
@@ -344,6 +371,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       {
         Frags<BF16, KB> FA;
         make_frags<BF16, KB>(FA, dy);
+        if (swrite) store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 1], srow, D, FA, quad);
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true>(
@@ -375,6 +403,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           FG.f[4 * m + 2] = v[2 * m]; FG.f[4 * m + 3] = v[2 * m + 1];
         }
       }
+      if (swrite) {
+        Frags<BF16, KB> Fg, Fb;
+#pragma unroll
+        for (int m = 0; m < KB; ++m) {
+          if constexpr (BF16) { Fg.f[m] = FG.f[2 * m]; Fb.f[m] = FG.f[2 * m + 1]; }
+          else { Fg.f[2 * m] = FG.f[4 * m]; Fg.f[2 * m + 1] = FG.f[4 * m + 1]; Fb.f[2 * m] = FG.f[4 * m + 2]; Fb.f[2 * m + 1] = FG.f[4 * m + 3]; }
+        }
+        store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 2], srow, D, Fg, quad);
+        store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 3], srow, D, Fb, quad);
+      }
       if (h + 1 < H) panel_gemm<2 * KB, NT, BF16, ST_GB>(dnh, FG, P, ring, gGB + h * PANEL_GG, pGB + (h + 1) * PANEL_GB, true, lane);
       else panel_gemm<2 * KB, NT, BF16, ST_DD>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, lane);
     }
@@ -393,6 +431,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) dnh[t][i] = r1 * (dnh[t][i] - m1 - nh[t][i] * m2) * gelu_grad_f(a3[t][i]);   // d a3
       make_frags<BF16, KB>(F, dnh);
+      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA3], srow, D, F, quad);
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -402,6 +441,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = ((relu_mask >> (4 * t + i)) & 1u) ? acc[t][i] : 0.f;             // d a2
       make_frags<BF16, KB>(F, acc);
+      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA2], srow, D, F, quad);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, gV1, pQ1, true, lane);                                    // d E_v
@@ -421,6 +461,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 E[NT];
       rff_embed<D, BF16>(E, inv, c_acq, lane, quad);
       make_frags<BF16, KB>(F, E);
+      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EQ], srow, D, F, quad);
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
@@ -453,6 +494,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       }
       Frags<BF16, KB> FA;
       make_frags<BF16, KB>(FA, acc);
+      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA1], srow, D, FA, quad);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       panel_gemm<KB, NT, BF16, ST_DD>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, lane);                 // d E_q
@@ -506,10 +548,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   }
 }
 
-template <int D, int H, bool BF16>
+template <int D, int H, bool BF16, bool STORE>
 static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
   using SM = PairBwdSmem<D, H, BF16>;
-  auto kern = enf_pair_bwd_kernel<D, H, BF16>;
+  auto kern = enf_pair_bwd_kernel<D, H, BF16, STORE>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL) != hipSuccess)
@@ -523,7 +565,7 @@ static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
 
 extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, const float* lse, const float* dybar, const float* delta, float* dlt,
-                                   hipStream_t st) {
+                                   void* const* store, hipStream_t st) {
   PairBwdArgs A;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;
   A.dlt = dlt; A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
@@ -532,8 +574,13 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
   int ns = 1;
   while (wgs * ns < 256 && ns * 2 <= ntiles) ns *= 2;
   A.nsplit = ns;
+  if (store)
+    for (int i = 0; i < ENF_NUM_STORE(m.H); ++i) A.store[i] = store[i];
 #define ENF_CASE(DD, HH)                                                                   \
-  if (m.D == DD && m.H == HH) return m.bf16 ? launch_pair_bwd<DD, HH, true>(A, st) : launch_pair_bwd<DD, HH, false>(A, st);
+  if (m.D == DD && m.H == HH) {                                                            \
+    if (store) return m.bf16 ? launch_pair_bwd<DD, HH, true, true>(A, st) : launch_pair_bwd<DD, HH, false, true>(A, st); \
+    return m.bf16 ? launch_pair_bwd<DD, HH, true, false>(A, st) : launch_pair_bwd<DD, HH, false, false>(A, st);         \
+  }
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)

@@ -4,7 +4,8 @@ Same constructor keywords (experiments/fitting/__init__.py:25-38), same ``init``
 call shapes as the Flax module, same parameter tree (names follow Flax's naming rules, SURVEY.md
 8a), same latent conventions.  ``apply`` runs the fused HIP path through the C-ABI
 (include/enf_hip.h); gradients w.r.t. the latents (p, a, gaussian_window) come from the
-hand-written HIP backward.  There is no eager / CPU path.
+hand-written HIP backward; when the weights require grad, ``apply`` takes the training path of
+``_train.py`` (same HIP pair kernels, weight gradients as well).  There is no eager / CPU path.
 """
 import ctypes
 import math
@@ -255,11 +256,8 @@ class EquivariantCrossAttentionNeF:
             return hit[1]
         desc = self._desc(1, 1, 1)
         _lib.check(lib.enf_check_desc(ctypes.byref(desc)))
-        shapes = self._expected_shapes()
         ts = [t.detach().to(torch.float32).contiguous() for t in ts]
-        for t, shp, path in zip(ts, shapes, TENSOR_PATHS):
-            if tuple(t.shape) != shp:
-                raise ValueError(f"parameter {'/'.join(path)} has shape {tuple(t.shape)}, expected {shp}")
+        self._check_shapes(ts)
         nbytes = lib.enf_packed_weight_bytes(ctypes.byref(desc))
         blob = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
         arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -267,6 +265,11 @@ class EquivariantCrossAttentionNeF:
         _lib.check(lib.enf_pack_weights(ctypes.byref(desc), arr, _ptr(blob), st))
         self._pack_cache["k"] = (key, blob, ts)   # keep the fp32 sources alive until the pack kernels ran
         return blob
+
+    def _check_shapes(self, ts):
+        for t, shp, path in zip(ts, self._expected_shapes(), TENSOR_PATHS):
+            if tuple(t.shape) != shp:
+                raise ValueError(f"parameter {'/'.join(path)} has shape {tuple(t.shape)}, expected {shp}")
 
     def _expected_shapes(self):
         D, H, C, O, I = self.num_hidden, self.num_heads, self.latent_dim, self.num_out, self.cross_attn_invariant.dim
@@ -300,10 +303,16 @@ class EquivariantCrossAttentionNeF:
             raise AssertionError("gaussian_window_size is required when use_gaussian_window=True")
         if sigma is not None and not torch.is_tensor(sigma):
             sigma = torch.full((p.shape[0], p.shape[1], 1), float(sigma), device=p.device)
-        packed = self.pack(params)
         x, p, a = x.float(), p.float(), a.float()
         if sigma is not None:
             sigma = sigma.float().reshape(p.shape[0], p.shape[1], 1)
+        ts = self.param_tensors(params)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+            # training path: gradients w.r.t. the weights as well (TR:255, NTR:304-339)
+            from . import _train
+            self._check_shapes(ts)
+            return _train.apply_train(self, ts, x, p, a, sigma)
+        packed = self.pack(params)
         return _EnfFunction.apply(x, p, a, sigma, self, packed)
 
     __call__ = apply

@@ -1,0 +1,236 @@
+"""Training path of the decoder: gradients w.r.t. the network weights.
+
+The reference differentiates ``nef.apply`` w.r.t. ``params['nef']`` with ``jax.value_and_grad``
+(experiments/fitting/trainers/pde_trainer.py:255, nonmaml_pde_trainer.py:304-339).  Here the
+per-pair chain -- all but ~3 % of the arithmetic -- stays in the HIP kernels
+(``enf_pair_forward`` / ``enf_pair_backward``, include/enf_hip.h); what is per-latent or per-query
+(the weight folds, the latent prologue, the tail after the softmax-weighted sum) is expressed as
+ordinary differentiable device ops around it so that autograd carries the gradient from the
+"effective" per-pair parameters and the latent table back to the Flax-named tensors.
+
+The backward kernel materialises each per-pair layer's input and delta (bf16 in bf16 mode), and
+every per-pair weight gradient is then one GEMM  dW = X^T delta  over the pair axis.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn.functional as Fnn
+
+from ... import _lib
+
+LN_EPS = 1e-6          # flax.linen.LayerNorm default (NEF:56, ECA:19)
+STORE_BUDGET_BYTES = 6 << 30   # bound on the materialised activations of one backward chunk
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def lt_layout(desc):
+    lib = _lib.load()
+    v = [ctypes.c_int(0) for _ in range(6)]
+    _lib.check(lib.enf_lt_layout(ctypes.byref(desc), *[ctypes.byref(t) for t in v]))
+    return dict(zip(("stride", "u", "v0", "pose", "wcoef", "c"), [t.value for t in v]))
+
+
+def _xt_dot(X, Dl):
+    """X^T @ Dl with fp32 accumulation and fp32 result (X, Dl: (P, D) bf16 or fp32)."""
+    if X.dtype == torch.float32:
+        return X.t() @ Dl
+    try:
+        return torch.mm(X.t(), Dl, out_dtype=torch.float32)
+    except (TypeError, RuntimeError, NotImplementedError):
+        acc = None
+        step = 1 << 16
+        for i in range(0, X.shape[0], step):
+            part = (X[i:i + step].t() @ Dl[i:i + step]).float()
+            acc = part if acc is None else acc + part
+        return acc
+
+
+class _PairFunction(torch.autograd.Function):
+    """ybar = softmax-weighted sum of the per-pair value chain; HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, lt, model, *eff):
+        lib = _lib.load()
+        B, N, _ = x.shape
+        Z = lt.shape[0] // B
+        H, D = model.num_heads, model.num_hidden
+        dev = lt.device
+        desc = model._desc(B, N, Z)
+        xb, xstride = model._x_arg(x)
+        lt_ = lt.detach().contiguous()
+        effc = [t.detach().to(torch.float32).contiguous() for t in eff]
+        blob = torch.empty(int(lib.enf_packed_weight_bytes(ctypes.byref(desc))), device=dev, dtype=torch.uint8)
+        arr = (ctypes.c_void_p * len(effc))(*[t.data_ptr() for t in effc])
+        st = _stream(dev)
+        _lib.check(lib.enf_pack_pair(ctypes.byref(desc), arr, _ptr(blob), st))
+        ybar = torch.empty((B, N, H * D), device=dev, dtype=torch.float32)
+        lse = torch.empty((B, N, H), device=dev, dtype=torch.float32)
+        _lib.check(lib.enf_pair_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(lt_), _ptr(blob), _ptr(ybar),
+                                        _ptr(lse), st))
+        ctx.model, ctx.xstride, ctx.dims = model, xstride, (B, N, Z)
+        ctx.need_w = any(ctx.needs_input_grad[3:])
+        ctx.save_for_backward(xb, lt_, blob, ybar, lse)
+        ctx._keep = effc          # fp32 sources stay alive until the pack kernels have run
+        return ybar
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dybar):
+        lib = _lib.load()
+        model = ctx.model
+        xb, lt, blob, ybar, lse = ctx.saved_tensors
+        B, N, Z = ctx.dims
+        H, D = model.num_heads, model.num_hidden
+        HD = H * D
+        dev = lt.device
+        st = _stream(dev)
+        dybar = dybar.contiguous().float()
+        delta = (dybar * ybar).view(B, N, H, D).sum(-1).contiguous()
+        dlt = torch.empty_like(lt)
+        stride = lt.shape[1]
+        if not ctx.need_w:
+            desc = model._desc(B, N, Z)
+            _lib.check(lib.enf_pair_backward(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(lt), _ptr(blob), _ptr(lse),
+                                             _ptr(dybar), _ptr(delta), _ptr(dlt), None, st))
+            return (None, dlt, None) + (None,) * _lib.ENF_NUM_PAIR_TENSORS
+
+        bf16 = model.precision in ("bf16", "bfloat16")
+        sdt = torch.bfloat16 if bf16 else torch.float32
+        ns = _lib.num_store(H)
+        per_b = Z * N * D * ns * (2 if bf16 else 4)
+        cb = max(1, min(B, STORE_BUDGET_BYTES // max(per_b, 1)))
+        store = torch.empty((ns, cb * Z * N, D), device=dev, dtype=sdt)
+        f32 = dict(device=dev, dtype=torch.float32)
+        gAQ1, gAV1, gAF, gAM = (torch.zeros((D, D), **f32) for _ in range(4))
+        gAGB = torch.zeros((D, 2 * HD), **f32)
+        gBQ1, gBV1, gBF, gBM = (torch.zeros(D, **f32) for _ in range(4))
+        gBGB = torch.zeros(2 * HD, **f32)
+        S = _lib
+        for b0 in range(0, B, cb):
+            nb = min(cb, B - b0)
+            desc = model._desc(nb, N, Z)
+            P = nb * Z * N
+            sl = [store[i, :P] for i in range(ns)]
+            arr = (ctypes.c_void_p * ns)(*[t.data_ptr() for t in sl])
+            xo = xb if ctx.xstride == 0 else xb[b0:]
+            _lib.check(lib.enf_pair_backward(ctypes.byref(desc), _ptr(xo), ctx.xstride, _ptr(lt[b0 * Z:]), _ptr(blob),
+                                             _ptr(lse[b0:]), _ptr(dybar[b0:]), _ptr(delta[b0:]), _ptr(dlt[b0 * Z:]),
+                                             arr, st))
+            gAQ1 += _xt_dot(sl[S.ENF_S_EQ], sl[S.ENF_S_DA1]); gBQ1 += sl[S.ENF_S_DA1].sum(0, dtype=torch.float32)
+            gAV1 += _xt_dot(sl[S.ENF_S_EV], sl[S.ENF_S_DA2]); gBV1 += sl[S.ENF_S_DA2].sum(0, dtype=torch.float32)
+            gAF += _xt_dot(sl[S.ENF_S_G1], sl[S.ENF_S_DA3]); gBF += sl[S.ENF_S_DA3].sum(0, dtype=torch.float32)
+            for h in range(H):
+                V, DA5, DG, DB = (sl[S.ENF_S_HEAD0 + 4 * h + i] for i in range(4))
+                gAM += _xt_dot(V, DA5); gBM += DA5.sum(0, dtype=torch.float32)
+                gAGB[:, h * D:(h + 1) * D] += _xt_dot(sl[S.ENF_S_NH], DG)
+                gAGB[:, HD + h * D:HD + (h + 1) * D] += _xt_dot(sl[S.ENF_S_NH], DB)
+                gBGB[h * D:(h + 1) * D] += DG.sum(0, dtype=torch.float32)
+                gBGB[HD + h * D:HD + (h + 1) * D] += DB.sum(0, dtype=torch.float32)
+        assert dlt.shape[1] == stride
+        # ENF_P_* order: AQ1,BQ1, AV1,BV1, AF,BF, AGB,BGB, AM,BM, COEFQ,COEFV (frozen: RFF:87-90)
+        return (None, dlt, None, gAQ1, gBQ1, gAV1, gBV1, gAF, gBF, gAGB, gBGB, gAM, gBM, None, None)
+
+
+def _ln(x, g, b):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + LN_EPS) * g + b
+
+
+def _gelu(x):
+    return Fnn.gelu(x, approximate="tanh")      # flax nn.gelu default
+
+
+def latent_table(model, W, p, a, sigma, lay):
+    """K1 as differentiable ops: stem, LayerNorm, k / v0, the logit fold (u, c), pose embedding
+    and window coefficient, laid out as the pair kernels' latent table (enf_lt_layout)."""
+    H, D = model.num_heads, model.num_hidden
+    B, Z = p.shape[:2]
+    inv = model.cross_attn_invariant
+    s = a @ W["stem_w"] + W["stem_b"]                                     # NEF:220
+    an = _ln(s, W["lna_g"], W["lna_b"])                                   # NEF:56 / ECB
+    k = (an @ W["k_w"] + W["k_b"]).view(B, Z, H, D)                       # ECA:93
+    v0 = an @ W["v_w"] + W["v_b"]                                         # ECA:94
+    scale = 1.0 / math.sqrt(D)                                            # ECA:59
+    qw = W["q_w"].view(D, H, D)
+    mu = scale * torch.einsum("ij,jhd->hid", W["rq_w2"], qw)              # (H, D_in, D) : logits = h1 . (mu_h k_h)
+    cvec = scale * (torch.einsum("j,jhd->hd", W["rq_b2"], qw) + W["q_b"].view(H, D))
+    u = torch.einsum("hid,bzhd->bzhi", mu, k).reshape(B, Z, H * D)
+    c = torch.einsum("hd,bzhd->bzh", cvec, k)
+    name = inv.name
+    zero = p.new_zeros(B, Z, 1)
+    if name == "ponita":
+        pose = torch.cat([p[..., :2], torch.cos(p[..., 2:3]), torch.sin(p[..., 2:3])], -1)
+    elif name in ("latitude_periodic", "polar_periodic"):
+        pose = torch.cat([p[..., :2], torch.sin(p[..., 1:2]), torch.cos(p[..., 1:2])], -1)
+    else:
+        pose = torch.cat([p[..., :3]] + [zero] * (4 - min(p.shape[-1], 3)), -1)
+    if sigma is None:
+        wc = p.new_ones(B, Z, 1)
+    elif name in ("latitude_periodic", "polar_periodic"):
+        wc = 1.0 / (2.0 * sigma * sigma)
+    else:
+        wc = 1.0 / (sigma * sigma)
+    parts = sorted([(lay["u"], u), (lay["v0"], v0), (lay["pose"], pose), (lay["wcoef"], wc), (lay["c"], c)],
+                   key=lambda t: t[0])
+    out, pos = [], 0
+    for off, t in parts:
+        if off > pos:
+            out.append(p.new_zeros(B, Z, off - pos))
+        out.append(t)
+        pos = off + t.shape[-1]
+    if pos < lay["stride"]:
+        out.append(p.new_zeros(B, Z, lay["stride"] - pos))
+    return torch.cat(out, -1).reshape(B * Z, lay["stride"])
+
+
+def effective_pair_params(model, W):
+    """The twelve ENF_P_* tensors from the Flax-named weights (exact folds)."""
+    return [W["rq_w1"], W["rq_b1"], W["rv_w1"], W["rv_b1"],
+            W["rv_w2"] @ W["f1_w0"], W["rv_b2"] @ W["f1_w0"] + W["f1_b0"],
+            W["f1_g"][:, None] * W["f1_w1"], W["f1_be"] @ W["f1_w1"] + W["f1_b1"],
+            W["mx_w0"], W["mx_b0"], W["rq_coef"].detach(), W["rv_coef"].detach()]
+
+
+def tail(model, W, ybar):
+    """Everything after the softmax-weighted sum.  The mixer's LayerNorm affine and Dense_1 are
+    applied after the sum (attention weights sum to one, so this equals the reference's order)."""
+    H, D = model.num_heads, model.num_hidden
+    B, N, _ = ybar.shape
+    y = ybar.view(B, N, H, D) * W["mx_g"] + W["mx_be"]
+    y = (y @ W["mx_w1"] + W["mx_b1"]).reshape(B, N, H * D)               # ECA:16-21 (mixer Dense_1)
+    y = y @ W["ao_w"] + W["ao_b"]                                         # ECA out_proj
+    f = _ln(_gelu(y @ W["ff_w0"] + W["ff_b0"]), W["ff_g"], W["ff_be"]) @ W["ff_w1"] + W["ff_b1"]
+    o = _gelu(f)                                                          # NEF:227-233
+    o = _gelu(o @ W["o0_w"] + W["o0_b"])
+    o = _gelu(o @ W["o2_w"] + W["o2_b"])
+    return o @ W["o4_w"] + W["o4_b"]
+
+
+W_NAMES = ["stem_w", "stem_b", "lna_g", "lna_b",
+           "rq_coef", "rq_w1", "rq_b1", "rq_w2", "rq_b2", "rv_coef", "rv_w1", "rv_b1", "rv_w2", "rv_b2",
+           "q_w", "q_b", "k_w", "k_b", "v_w", "v_b",
+           "f1_w0", "f1_b0", "f1_g", "f1_be", "f1_w1", "f1_b1", "mx_w0", "mx_b0", "mx_g", "mx_be", "mx_w1", "mx_b1",
+           "ao_w", "ao_b", "ff_w0", "ff_b0", "ff_g", "ff_be", "ff_w1", "ff_b1",
+           "o0_w", "o0_b", "o2_w", "o2_b", "o4_w", "o4_b"]      # ENF_W_* order
+assert len(W_NAMES) == _lib.ENF_NUM_TENSORS
+
+
+def apply_train(model, tensors, x, p, a, sigma):
+    """nef.apply differentiable w.r.t. every weight tensor and the latents."""
+    W = dict(zip(W_NAMES, tensors))
+    desc = model._desc(p.shape[0], x.shape[1], p.shape[1])
+    _lib.check(_lib.load().enf_check_desc(ctypes.byref(desc)))
+    lay = lt_layout(desc)
+    lt = latent_table(model, W, p, a, sigma, lay)
+    eff = effective_pair_params(model, W)
+    ybar = _PairFunction.apply(x, lt, model, *eff)
+    return tail(model, W, ybar)

@@ -131,6 +131,44 @@ int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, co
                          const float* lse, const float* dout, float* dp, float* da, float* dsigma,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training path: gradients w.r.t. the network weights (value_and_grad over params['nef'],
+ * pde_trainer.py:255; nonmaml_pde_trainer.py:304-339).  The per-pair chain (97 % of the FLOPs)
+ * stays in HIP; folds, latent prologue and tail -- per-latent / per-query work -- are run by the
+ * host framework as differentiable ops around these two entry points.
+ *   latent table `lt` (B*Z rows, enf_lt_layout): [ u (H*D) | v0 (H*D) | pose (4) | wcoef | pad | c (H) | pad ]
+ *     u, c   : att[n,z,h] = h1[n,z,:].u[z,h,:] + c[z,h]        (fold 1)
+ *     v0     : a_to_v(a_norm)                                   (ECA:94)
+ *     pose   : periodic/rel/abs/norm (p0,p1,p2,-); ponita (px,py,cos t,sin t); sphere (phi,theta,sin theta,cos theta)
+ *     wcoef  : 1/sigma^2 (sphere: 1/(2 sigma^2))
+ * ------------------------------------------------------------------------------------------- */
+enum {   /* effective per-pair parameters, plain fp32, kernels (in, out) */
+  ENF_P_AQ1 = 0, ENF_P_BQ1,   /* query RFFNet layers_0                         (D,D), (D)  */
+  ENF_P_AV1, ENF_P_BV1,       /* value RFFNet layers_0                         (D,D), (D)  */
+  ENF_P_AF, ENF_P_BF,         /* linear_final . inv_emb_to_v.Dense_0 (fold 2)  (D,D), (D)  */
+  ENF_P_AGB, ENF_P_BGB,       /* diag(LN.scale) Dense_1, LN.bias Dense_1 + b; Flax column order [gamma (HD) | beta (HD)]  (D,2HD), (2HD) */
+  ENF_P_AM, ENF_P_BM,         /* inv_emb_cond_mixer.Dense_0                    (D,D), (D)  */
+  ENF_P_COEFQ, ENF_P_COEFV,   /* RFF coefficients                              (I, D/2)    */
+  ENF_NUM_PAIR_TENSORS
+};
+/* Per-pair activations / deltas the backward can materialise (rows = (b*Z + z)*N + n, D columns,
+ * bf16 in ENF_PREC_BF16 and fp32 in ENF_PREC_F32) so that every per-pair weight gradient is a plain
+ * GEMM dW = X^T delta over the pair axis:   AQ1: EQ^T DA1   AV1: EV^T DA2   AF: G1^T DA3
+ *   AGB[:, gamma_h|beta_h]: NH^T DG_h | NH^T DB_h     AM: sum_h V_h^T DA5_h    biases: column sums of delta */
+enum { ENF_S_EQ = 0, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0 /* + 4h: V, DA5, DG, DB */ };
+#define ENF_NUM_STORE(H) (7 + 4 * (H))
+
+int enf_lt_layout(const EnfDesc* d, int* stride, int* off_u, int* off_v0, int* off_pose, int* off_wcoef, int* off_c);
+int enf_pack_pair(const EnfDesc* d, const float* const* pair_tensors, void* packed, void* stream);
+/* K2 alone: lt -> ybar (B,N,H*D), lse (B,N,H) */
+int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                     float* ybar, float* lse, void* stream);
+/* K3 alone: d ybar, delta[n,h] = d ybar . ybar, lse -> d lt (same layout as lt, overwritten);
+ * `store` = NULL or ENF_NUM_STORE(H) device buffers of B*Z*N rows (see ENF_S_*). */
+int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                      const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,121 @@
+"""Weight-gradient parity: the training path (HIP pair kernels + per-pair dW GEMMs + differentiable
+prologue / tail) against fp64 autograd of the torch oracle over every tensor of the parameter
+tree -- what the reference gets from jax.value_and_grad over params['nef']
+(pde_trainer.py:255, nonmaml_pde_trainer.py:304-339)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import enf_ref_np as R
+from oracle import enf_ref_torch as T
+from tests.helpers import make_cfg, make_inputs, build_nef
+from enf_pde_amd.enf.models import TENSOR_PATHS
+
+pytestmark = pytest.mark.gpu
+
+# relative L2 error per tensor; tensors whose reference gradient is ~0 are compared absolutely.
+# bf16: typical tensors sit at ~1 %.  The two relu layers are the outliers (3 % value branch, 6-13 %
+# query branch): a pre-activation within bf16 noise of zero flips its relu mask, an O(1) change of
+# that element's delta, and in the query branch the deltas additionally cancel over z
+# (sum_z dlogit = 0).  Measured per tensor with scripts/wgrad_err.py; f32 mode has no such effect.
+TOL = {"f32": 5e-4, "bf16": 2e-1}
+
+
+def _get(tree, path):
+    for k in path:
+        tree = tree[k]
+    return tree
+
+
+def ref(prm, cfg, x, p, a, s, w):
+    tp = T.to_torch(prm, torch.float64, requires_grad=True)
+    tpp, ta, ts = (torch.tensor(v, requires_grad=True) for v in (p, a, s))
+    out = T.nef_apply(tp, cfg, torch.tensor(x), tpp, ta, ts)
+    (out * torch.tensor(w)).sum().backward()
+    g = lambda t: np.zeros(tuple(t.shape)) if t.grad is None else t.grad.numpy()
+    return out.detach().numpy(), [g(_get(tp["params"], path)) for path in TENSOR_PATHS], g(tpp), g(ta), g(ts)
+
+
+def hip(cuda, nef, prm, x, p, a, s, w):
+    params = nef.load_params(prm, device=cuda)
+    ts_ = nef.param_tensors(params)
+    for t in ts_:
+        t.requires_grad_(True)
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    tp, ta, ts = t(p, True), t(a, True), t(s, True)
+    out = nef.apply(params, t(x), tp, ta, ts)
+    (out * t(w)).sum().backward()
+    torch.cuda.synchronize()
+    g = lambda v: np.zeros(tuple(v.shape)) if v.grad is None else v.grad.cpu().numpy().astype(np.float64)
+    return out.detach().cpu().numpy(), [g(v) for v in ts_], g(tp), g(ta), g(ts)
+
+
+def check(cuda, cfg, B, N, Z, precision, seed=0):
+    prm = R.init_params(seed, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, B, N, Z, seed + 1)
+    w = np.random.default_rng(seed + 2).standard_normal((B, N, cfg["num_out"]))
+    ro, rg, rp, ra, rs = ref(prm, cfg, x, p, a, s, w)
+    nef = build_nef(cfg, precision)
+    ho, hg, hp, ha, hs = hip(cuda, nef, prm, x, p, a, s, w)
+    tol = TOL[precision]
+    assert np.abs(ho - ro).max() / np.abs(ro).max() < (2e-5 if precision == "f32" else 3e-2)
+    gmax = max(np.linalg.norm(g) for g in rg)
+    bad = []
+    for path, g, r in zip(TENSOR_PATHS, hg, rg):
+        nr = np.linalg.norm(r)
+        if path[-1] == "coefficients":                       # frozen: stop_gradient (rff.py:87-90)
+            assert np.all(g == 0) and nr == 0
+            continue
+        err = np.linalg.norm(g - r) / nr if nr > 1e-6 * gmax else np.linalg.norm(g - r) / gmax
+        if not (np.isfinite(err) and err < tol):
+            bad.append(("/".join(path), err))
+    assert not bad, (precision, bad)
+    for name, g, r in (("p", hp, rp), ("a", ha, ra), ("sigma", hs, rs)):
+        if np.linalg.norm(r) > 0:
+            e = np.linalg.norm(g - r) / np.linalg.norm(r)
+            assert e < tol, (name, e)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("invariant", ["rel_pos_periodic", "ponita", "polar_periodic"])
+def test_weight_grads_invariants(cuda, invariant, precision):
+    cfg = make_cfg(invariant, D=128, H=2, C=16, O=3, freq=(0.5, 1.0))
+    check(cuda, cfg, B=2, N=70, Z=9, precision=precision)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("D,H,C,O,Z,N", [(128, 2, 16, 1, 64, 256), (64, 2, 16, 1, 16, 100), (128, 1, 32, 3, 18, 33),
+                                         (64, 1, 8, 2, 4, 32)])
+def test_weight_grads_shapes(cuda, D, H, C, O, Z, N, precision):
+    cfg = make_cfg("rel_pos_periodic", D=D, H=H, C=C, O=O)
+    check(cuda, cfg, B=3, N=N, Z=Z, precision=precision, seed=D + Z)
+
+
+def test_weight_grads_chunked_store(cuda, monkeypatch):
+    """The backward materialises activations in batch chunks; a tiny budget forces several chunks."""
+    from enf_pde_amd.enf.models import _train
+    cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=16, O=1)
+    per_b = 8 * 48 * 64 * (7 + 8) * 4
+    monkeypatch.setattr(_train, "STORE_BUDGET_BYTES", 2 * per_b)
+    check(cuda, cfg, B=5, N=48, Z=8, precision="f32", seed=3)
+
+
+def test_training_path_matches_inference_path(cuda):
+    """Same outputs and latent gradients whichever path apply() takes."""
+    cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
+    prm = R.init_params(5, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 2, 96, 16, 6)
+    nef = build_nef(cfg, "f32")
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    res = []
+    for train in (False, True):
+        params = nef.load_params(prm, device=cuda)
+        if train:
+            for w in nef.param_tensors(params):
+                w.requires_grad_(True)
+        tp, ta, ts = t(p, True), t(a, True), t(s, True)
+        out = nef.apply(params, t(x), tp, ta, ts)
+        out.square().sum().backward()
+        res.append((out.detach(), tp.grad, ta.grad, ts.grad))
+    for u, v in zip(*res):
+        assert torch.allclose(u, v, rtol=2e-3, atol=2e-4 * float(v.abs().max()))
