@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libenf_hip.so")
+LIB_PATH = os.environ.get("ENF_HIP_LIB") or os.path.join(_HERE, "libenf_hip.so")   # ENF_HIP_LIB: A/B builds (scripts/build_variant.sh)
 
 ENF_NUM_TENSORS = 46
 PREC = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
@@ -15,7 +15,7 @@ INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic"
 EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
            "enf_backward_latents", "enf_forward_stages", "enf_lt_layout", "enf_pack_pair", "enf_pair_forward",
-           "enf_pair_backward"]
+           "enf_pair_backward", "enf_pair_scratch_bytes", "enf_set_zfold"]
 ENF_NUM_PAIR_TENSORS = 12          # ENF_P_* of include/enf_hip.h
 (ENF_S_EQ, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0) = range(8)
 
@@ -66,7 +66,11 @@ def load():
     ip = ctypes.POINTER(ci)
     lib.enf_lt_layout.argtypes = [dp, ip, ip, ip, ip, ip, ip]
     lib.enf_pack_pair.argtypes = [dp, ctypes.POINTER(vp), vp, vp]
-    lib.enf_pair_forward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp]
+    lib.enf_set_zfold.restype = None
+    lib.enf_set_zfold.argtypes = [ci]
+    lib.enf_pair_scratch_bytes.restype = sz
+    lib.enf_pair_scratch_bytes.argtypes = [dp]
+    lib.enf_pair_forward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, sz, vp]
     lib.enf_pair_backward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp), vp]
     for name in ("enf_debug_gemm", "enf_debug_pack"):
         getattr(lib, name).restype = ci

@@ -50,10 +50,21 @@ DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
   }
 }
 
+#include "enf_gemm_asm.h"
+#ifndef ENF_ASM_GEMM
+#define ENF_ASM_GEMM 1
+#endif
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 // acc[mt] += W^T[16 mt .., :] X for MTS out-tiles whose fragments start at `lds`.
 // Panel order (enf_pack.hip): bf16 [mt][blk][lane] x 16 B; fp32 [mt][in-tile][lane] x 16 B.
 template <bool BF16, int KB, int MTS>
 DEV void gemm_stage(f32x4* acc, const Frags<BF16, KB>& F, const char* lds, int lane) {
+  if constexpr (BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS>::available) {
+    // hand-scheduled stage: NBUF fragment reads in flight, MFMAs round-robin over the accumulators
+    GemmStageAsm<KB, MTS>::run(acc, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(lds) + (lane << 4)));
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MTS; ++mt) {
     if constexpr (BF16) {
@@ -149,8 +160,6 @@ DEV __amdgpu_buffer_rsrc_t make_blob_rsrc(const char* blob, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(blob), 0, bytes, 0x00020000);
 }
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
 template <int BYTES, int NW = NWAVES>
 DEV void stage_issue(__amdgpu_buffer_rsrc_t rs, unsigned src_off, char* dst, int wave, int lane) {
   static_assert(BYTES % 1024 == 0 && BYTES <= STAGE_MAX, "stage size");
@@ -166,7 +175,24 @@ DEV void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Panel = (MTOUT out-tiles of 16 rows) x (KBIN in-blocks of 32) of A-operand fragments, streamed
 // through a 2-slot LDS ring (slot stride STAGE_MAX) in stages of MTS out-tiles.
-struct Pipe { __amdgpu_buffer_rsrc_t rs; int cur; int wave; };
+// `early` (wave-uniform; opt-in through first_stage<.., ANTI = true>): the upper half of the workgroup's
+// waves -- the SIMD-mates of the lower half -- take each stage's barrier BEFORE its MFMAs instead of
+// after them.  Every wave still meets every barrier and reads a ring slot only inside that slot's
+// window, but inside a window one wave of a SIMD runs [MFMA, epilogue] while its mate runs
+// [epilogue, MFMA]: the matrix pipe and the vector ALU work at the same time instead of in turns.
+// A kernel that opts in must end its stage sequence with pipe_finish().
+// Stage offsets with STAGE_RS2 set address the second buffer resource `rs2` (the per-latent panels of the
+// z-fold forward path) instead of the weight blob `rs`; a kernel without one sets rs2 = rs.
+constexpr unsigned STAGE_RS2 = 0x80000000u;
+struct Pipe { __amdgpu_buffer_rsrc_t rs, rs2; int cur; int wave; bool early; };
+template <int BYTES, int NW = NWAVES>
+DEV void stage_issue_p(const Pipe& P, unsigned src_off, char* dst, int lane) {
+  if (src_off & STAGE_RS2) stage_issue<BYTES, NW>(P.rs2, src_off & ~STAGE_RS2, dst, P.wave, lane);
+  else stage_issue<BYTES, NW>(P.rs, src_off, dst, P.wave, lane);
+}
+DEV void stage_open(const Pipe& P) { if (P.early) { stage_wait(); __syncthreads(); } }
+DEV void stage_close(Pipe& P) { if (!P.early) { stage_wait(); __syncthreads(); } P.cur ^= 1; }
+DEV void pipe_finish(const Pipe& P) { if (P.early) { stage_wait(); __syncthreads(); } }
 
 template <int KBIN, int MTOUT, bool BF16> struct PanelCfg {
   static constexpr int MT_BYTES = KBIN * (BF16 ? 1024 : 2048);
@@ -188,12 +214,11 @@ DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, ch
   using C = PanelCfg<KBIN, MTOUT, BF16>;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE, NW>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES, NW>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    stage_open(P);
+    if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
+    else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     if (active) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane);
-    stage_wait();
-    __syncthreads();
-    P.cur ^= 1;
+    stage_close(P);
   }
 }
 
@@ -205,8 +230,9 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
   using C = PanelCfg<KBIN, MTOUT, BF16>;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE, NW>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES, NW>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    stage_open(P);
+    if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
+    else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     const char* slot = ring + P.cur * STAGE_MAX;
     if constexpr (TRANS) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, slot, lane);
 #pragma unroll
@@ -215,18 +241,18 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
       gemm_tile_flip<BF16, KBIN>(af, F, slot, mt, lane);
       flip(sp * C::MTS + mt, af);
     }
-    stage_wait();
-    __syncthreads();
-    P.cur ^= 1;
+    stage_close(P);
   }
 }
 
-template <int BYTES, int NW = NWAVES> DEV void first_stage(Pipe& P, char* ring, unsigned panel, int wave, int lane) {
+template <int BYTES, int NW = NWAVES, bool ANTI = false>
+DEV void first_stage(Pipe& P, char* ring, unsigned panel, int wave, int lane) {
   P.cur = 0;
   P.wave = __builtin_amdgcn_readfirstlane(wave);
-  stage_issue<BYTES, NW>(P.rs, panel, ring, P.wave, lane);
-  stage_wait();
-  __syncthreads();
+  P.early = ANTI && P.wave >= NW / 2;
+  stage_issue_p<BYTES, NW>(P, panel, ring, lane);
+  if constexpr (ANTI) __syncthreads();      // publishes the kernel's LDS constants to the early waves
+  if (!P.early) { stage_wait(); __syncthreads(); }
 }
 
 // LayerNorm statistics over the NT*16 features of this lane's column: biased variance, eps 1e-6,

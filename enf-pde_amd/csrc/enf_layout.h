@@ -15,6 +15,7 @@
 //   WF1 = diag(ffn.LN.scale) @ ffn.Dense_1                             (ECA:19-20)
 #pragma once
 #include <stddef.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/enf_hip.h"
 
@@ -91,6 +92,10 @@ struct EnfLayout {
   size_t p_af, p_agb, p_wb, p_wf1, p_tmp, p_o4;   // DxD, Dx2HD, HDxHD, HDxHD, HDxHD, Dx(32*OB)
   size_t p_mxw;                         // DxD: diag(mixer LN scale) @ mixer Dense_1
   size_t p_mxb;                         // D: mixer LN bias @ Dense_1 + Dense_1 bias
+  // ---- latent-independent parts of the per-latent mixer-input fold (enf_wz.hip)
+  size_t p_wbmt;                        // H x (D x D): [h][k][i] = sum_j Wbeta_h[i][j] AM[j][k]
+  size_t p_cb;                          // H x D:       [h][k]    = sum_j bbeta_h[j] AM[j][k] + bm[k]
+  size_t p_opbg;                        // H x D:       [h][j]    = 1 + bgamma_h[j]
   size_t total;
 };
 
@@ -125,6 +130,7 @@ inline EnfLayout enf_layout(const EnfDims& m) {
   L.p_af = take(f * D * D); L.p_agb = take(f * D * 2 * HD); L.p_wb = take(f * HD * HD);
   L.p_wf1 = take(f * HD * HD); L.p_tmp = take(f * HD * HD); L.p_o4 = take(f * D * OP);
   L.p_mxw = take(f * D * D); L.p_mxb = take(f * D);
+  L.p_wbmt = take(f * H * D * D); L.p_cb = take(f * H * D); L.p_opbg = take(f * H * D);
   L.total = o;
   return L;
 }
@@ -138,6 +144,19 @@ ENF_HD inline int enf_lt_off_pose(int H, int D) { return 2 * H * D; }
 ENF_HD inline int enf_lt_off_wcoef(int H, int D) { return 2 * H * D + 4; }
 ENF_HD inline int enf_lt_off_c(int H, int D) { return 2 * H * D + 8; }
 
+// Forward pair kernel variant.  "z-fold": all 8 waves of a workgroup walk the latents together (one
+// latent per step, 128 queries per workgroup), which lets FiLM and the mixer's first Dense collapse
+// into ONE per-latent D x D matrix  W_zh = (Wgamma_h diag(v0_zh) + Wbeta_h) AM  (no nonlinearity
+// sits between them), built by enf_wz_kernel into `wz` before the pair kernel runs.  It needs
+// enough 128-query workgroups to fill the chip; below that the latent-split variant runs.
+// ENF_ZFOLD=0 / 1 in the environment, or enf_set_zfold(), forces the choice (tests).
+int enf_zfold_mode();   // enf_api.hip: -1 heuristic, 0 / 1 forced (ENF_ZFOLD in the environment, or enf_set_zfold)
+inline bool enf_use_zfold(const EnfDims& m) {
+  const int mode = enf_zfold_mode();
+  if (mode >= 0) return mode == 1;
+  return (long long)((m.N + 127) / 128) * m.B >= 192;
+}
+
 struct EnfWorkspace {
   size_t lt;        // B*Z*lt_stride floats: latent table
   size_t an;        // B*Z*(D + D + 2) floats: stem output, a_norm, LN mean/rstd (prologue backward)
@@ -148,6 +167,8 @@ struct EnfWorkspace {
   size_t delta;     // B*N*H   sum_d dybar*ybar (backward)
   size_t tail_act;  // B*N*(2*HD + 2*D + 2) tail pre-activations + LN stats (backward recompute cache)
   size_t dlt;       // B*Z*lt_stride floats: gradient of the latent table (backward)
+  size_t wz;        // B*Z*H packed D x D panels: per-latent mixer-input matrices (z-fold forward only)
+  size_t wzb;       // B*Z*H*D floats: their bias vectors
   size_t total;
 };
 
@@ -166,6 +187,9 @@ inline EnfWorkspace enf_workspace(const EnfDims& m) {
   W.delta = take(f * BN * m.H);
   W.tail_act = take(f * BN * (2 * m.HD + 2 * m.D + 2));
   W.dlt = take(f * BZ * enf_lt_stride(m.H, m.D));
+  const bool zf = enf_use_zfold(m);
+  W.wz = take(zf ? BZ * m.H * enf_panel_bytes(m.D, m.D, m.bf16) : 0);
+  W.wzb = take(zf ? f * BZ * m.HD : 0);
   W.total = o;
   return W;
 }

@@ -91,6 +91,26 @@ __global__ void pack_panel_kernel(void* dst, const float* W, int ldw, int R, int
   else reinterpret_cast<float*>(dst)[e] = v;
 }
 
+// latent-independent parts of the per-latent fold W_zh = (Wgamma_h diag(v0) + Wbeta_h) AM (enf_wz.hip):
+//   wbmt[h][k][i] = sum_j Wbeta_h[i][j] AM[j][k];  cb[h][k] = sum_j bbeta_h[j] AM[j][k] + bm[k];  opbg[h][j] = 1 + bgamma_h[j]
+// agb / bgb are in the [g g b b] interleaved column order of reorder_gb_kernel.
+__global__ void wz_const_kernel(float* wbmt, float* cb, float* opbg, const float* agb, const float* bgb, const float* am,
+                                const float* bm, int H, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y, h = blockIdx.z;
+  if (i >= D) return;
+  const int HD2 = 2 * H * D;
+  auto bcol = [&](int j) { return h * 2 * D + 64 * (j >> 5) + 32 + (j & 31); };   // beta column of feature j
+  float s = 0.f;
+  for (int j = 0; j < D; ++j) s = fmaf(agb[(size_t)i * HD2 + bcol(j)], am[(size_t)j * D + k], s);
+  wbmt[((size_t)h * D + k) * D + i] = s;
+  if (i == 0) {
+    float c = bm[k];
+    for (int j = 0; j < D; ++j) c = fmaf(bgb[bcol(j)], am[(size_t)j * D + k], c);
+    cb[h * D + k] = c;
+  }
+  if (k == 0) opbg[h * D + i] = 1.0f + bgb[h * 2 * D + 64 * (i >> 5) + (i & 31)];
+}
+
 static inline int mm(hipStream_t st, float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N,
                      int K, float alpha, const float* addv, int acc) {
   dim3 g((N + 127) / 128, M);
@@ -132,7 +152,10 @@ static int pack_pair_panels(hipStream_t st, char* blob, const EnfLayout& L, cons
   // d inv[c] = sum_t 2 pi coeff[c][t] d t[t]  (RFF:92)
   if ((rc = pack_panel(st, blob, L.gcq, coefq, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
   if ((rc = pack_panel(st, blob, L.gcv, coefv, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
-  return ENF_OK;
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
+  hipLaunchKernelGGL(wz_const_kernel, dim3((D + 63) / 64, D, H), dim3(64), 0, st, F(L.p_wbmt), F(L.p_cb), F(L.p_opbg), agb,
+                     F(L.bgb), am, F(L.bm), H, D);
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
 
 // Pack ONLY what the pair kernels (enf_pair_forward / enf_pair_backward) read, from the "effective"

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 
   Pipe P;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
+  P.rs2 = P.rs;
   first_stage<ST_DD>(P, ring, pQ1, wave, lane);
 
   // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature

@@ -20,8 +20,9 @@ DEV void gb_panel(f32x4 (&v)[D / 16], f32x4 (&opg)[KEEP ? D / 16 : 1], const Fra
   constexpr int KB = D / 32, MTS = C::MTS;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
-    if (sp + 1 < C::SPP) stage_issue<C::STAGE, NW>(P.rs, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
-    else if (next != NO_STAGE) stage_issue<NEXT_BYTES, NW>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
+    stage_open(P);
+    if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
+    else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     f32x4 t[MTS];
 #pragma unroll
     for (int j = 0; j < MTS; ++j) t[j] = rowvec(bias, sp * MTS + j, quad);
@@ -40,9 +41,7 @@ DEV void gb_panel(f32x4 (&v)[D / 16], f32x4 (&opg)[KEEP ? D / 16 : 1], const Fra
         }
       }
     }
-    stage_wait();
-    __syncthreads();
-    P.cur ^= 1;
+    stage_close(P);
   }
 }
 

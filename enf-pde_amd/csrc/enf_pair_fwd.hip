@@ -26,8 +26,29 @@ struct PairFwdArgs {
   const float* x; long long x_bstride;
   const float* lt; const char* blob; EnfLayout L;
   float* ybar; float* lse;
+  const char* wz; const float* wzb;       // z-fold only: per-latent mixer-input panels / biases (enf_wz.hip)
   int B, N, Z, dx, inv, use_window, qg;   // qg: query groups per workgroup (1,2,4,8); ZS = 8/qg
 };
+
+// Debug build only (-DENF_STAMPS): s_memtime stamps of the first iterations of workgroup 0, one row per
+// wave, read back with enf_debug_read_stamps(); the buffer is read by no kernel code (MI355X_MICROARCH.md).
+#ifdef ENF_STAMPS
+__device__ unsigned long long enf_stamps[8 * 4 * 24];
+#define STAMP(k)                                                                                              \
+  do {                                                                                                        \
+    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && it < 4)                                            \
+      enf_stamps[(wave * 4 + it) * 24 + (k)] = __builtin_amdgcn_s_memtime();                                  \
+  } while (0)
+extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(enf_stamps), sizeof(enf_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+#ifndef ENF_ANTIPHASE
+#define ENF_ANTIPHASE true
+#endif
 
 template <int D, int H, bool BF16> struct PairSmem {
   static constexpr int RING = 0;                                   // 2 slots
@@ -40,12 +61,15 @@ template <int D, int H, bool BF16> struct PairSmem {
   static_assert(4 * YBYTES <= 2 * STAGE_MAX, "combine buffer must fit in the ring");
 };
 
-template <int D, int H, bool BF16>
+// ZFOLD: qg = 8 (every wave walks all latents, the 8 waves in step), and per head the gamma/beta GEMM, FiLM
+// and the mixer's first Dense are ONE D x D GEMM with the per-latent matrix W_zh of enf_wz.hip:
+//   a5_h = W_zh^T n + c_zh      (5 D x D GEMMs per pair instead of 9 D x D equivalents)
+template <int D, int H, bool BF16, bool ZFOLD>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A) {
   using Cfg = PairCfg<D, BF16>;
   using SM = PairSmem<D, H, BF16>;
   constexpr int KB = Cfg::KB, NT = Cfg::NT;
-  constexpr int ST_DD = Cfg::DD::STAGE, ST_GB = Cfg::GB::STAGE, PANEL_GB = Cfg::GB::BYTES;
+  constexpr int ST_DD = Cfg::DD::STAGE, ST_GB = Cfg::GB::STAGE, PANEL_GB = Cfg::GB::BYTES, PANEL_DD = Cfg::DD::BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem + SM::RING;
   float* cst = reinterpret_cast<float*>(smem + SM::CONSTS);
@@ -71,7 +95,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 
   Pipe P;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
-  first_stage<ST_DD>(P, ring, pQ1, wave, lane);
+  if constexpr (ZFOLD) P.rs2 = make_blob_rsrc(A.wz + (size_t)b * A.Z * H * PANEL_DD, (unsigned)(A.Z * H * PANEL_DD));
+  else P.rs2 = P.rs;
+  first_stage<ST_DD, NWAVES, ENF_ANTIPHASE>(P, ring, pQ1, wave, lane);
 
   // softmax state against a per-column reference logit (the first one seen); fp32 accumulators
   float sm_m[H], sm_l[H], sm_c[H];
@@ -89,10 +115,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
     const int z = it * ZS + zs;
     const bool active = z < A.Z;
     const float* ltrow = A.lt + ((size_t)b * A.Z + (active ? z : A.Z - 1)) * ltstride;
+    STAMP(0);
     // per-latent vectors u | v0 -> wave-private LDS
+    if constexpr (ZFOLD) {      // u from the latent table, c_zh from the fold kernel
+      const float* czrow = A.wzb + ((size_t)b * A.Z + z) * (H * D);
 #pragma unroll
-    for (int i = lane * 4; i < 2 * H * D; i += 256)
-      *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+      for (int i = lane * 4; i < H * D; i += 256) {
+        *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+        *reinterpret_cast<f32x4*>(zv + H * D + i) = *reinterpret_cast<const f32x4*>(czrow + i);
+      }
+    } else {
+#pragma unroll
+      for (int i = lane * 4; i < 2 * H * D; i += 256)
+        *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+    }
     const f32x4 pz = *reinterpret_cast<const f32x4*>(ltrow + enf_lt_off_pose(H, D));
     const float wcoef = ltrow[enf_lt_off_wcoef(H, D)];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -109,7 +145,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
+      STAMP(1);
       panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pQ1, pV1, active, lane);
+      STAMP(2);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float s = 0.f;
@@ -122,13 +160,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
         logit[h] = xquad_sum(s) + ltrow[enf_lt_off_c(H, D) + h] + win;
       }
     }
+    STAMP(3);
     {  // ---------------- value branch: RFFNet layer, folded (linear_final . Dense_0), gelu, LN
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bv1, t, quad);
+      STAMP(4);
       panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pV1, pF, active, lane);
+      STAMP(5);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -136,7 +177,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
       make_frags<BF16, KB>(F, acc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bf, t, quad);
-      panel_gemm<KB, NT, BF16, ST_GB>(acc, F, P, ring, pF, pGB, active, lane);
+      STAMP(6);
+      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(z * H * PANEL_DD), active, lane);
+      else panel_gemm<KB, NT, BF16, ST_GB>(acc, F, P, ring, pF, pGB, active, lane);
+      STAMP(7);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -149,18 +193,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = fmaf(acc[t][i], rstd, nmr);
       make_frags<BF16, KB>(F, acc);   // F = normalised f, shared by all heads' gamma/beta panels
+      STAMP(8);
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      f32x4 v[NT], dummy[1];
-      gb_panel<D, BF16, ST_DD, false>(v, dummy, F, P, ring, pGB + h * PANEL_GB, pM, active, c_bgb + 2 * h * D,
-                                      zv + H * D + h * D, lane, quad);
-      Frags<BF16, KB> FV;
-      make_frags<BF16, KB>(FV, v);
+      f32x4 v[NT];
+      if constexpr (ZFOLD) {
+        const unsigned wzh = STAGE_RS2 | (unsigned)((z * H + h) * PANEL_DD);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) v[t] = rowvec(c_bm, t, quad);
-      if (h + 1 < H) panel_gemm<KB, NT, BF16, ST_GB>(v, FV, P, ring, pM, pGB + (h + 1) * PANEL_GB, active, lane);
-      else panel_gemm<KB, NT, BF16, ST_DD>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane);
+        for (int t = 0; t < NT; ++t) v[t] = rowvec(zv + H * D + h * D, t, quad);
+        STAMP(10 + 4 * h);
+        panel_gemm<KB, NT, BF16, ST_DD>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
+                                        active, lane);
+      } else {
+        f32x4 dummy[1];
+        gb_panel<D, BF16, ST_DD, false>(v, dummy, F, P, ring, pGB + h * PANEL_GB, pM, active, c_bgb + 2 * h * D,
+                                        zv + H * D + h * D, lane, quad);
+        STAMP(9 + 4 * h);
+        Frags<BF16, KB> FV;
+        make_frags<BF16, KB>(FV, v);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = rowvec(c_bm, t, quad);
+        STAMP(10 + 4 * h);
+        if (h + 1 < H) panel_gemm<KB, NT, BF16, ST_GB>(v, FV, P, ring, pM, pGB + (h + 1) * PANEL_GB, active, lane);
+        else panel_gemm<KB, NT, BF16, ST_DD>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane);
+      }
+      STAMP(11 + 4 * h);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -190,9 +248,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 #pragma unroll
           for (int i = 0; i < 4; ++i) Y[h][t][i] = fmaf(w, v[t][i], Y[h][t][i]);
       }
+      STAMP(12 + 4 * h);
     }
   }
 
+  pipe_finish(P);
   // ---- combine the ZS latent splits of each query group (all staging is finished: ring is free)
   if (quad == 0) {
 #pragma unroll
@@ -262,10 +322,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
   }
 }
 
-template <int D, int H, bool BF16>
+template <int D, int H, bool BF16, bool ZFOLD>
 static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   using SM = PairSmem<D, H, BF16>;
-  auto kern = enf_pair_fwd_kernel<D, H, BF16>;
+  auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL) != hipSuccess)
@@ -277,17 +337,29 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
+extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, hipStream_t);
+
+// wz / wzb: scratch for the z-fold variant (enf_workspace: W.wz, W.wzb), or NULL for the latent-split variant
 extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
-                                   const float* lt, float* ybar, float* lse, hipStream_t st) {
+                                   const float* lt, float* ybar, float* lse, char* wz, float* wzb, hipStream_t st) {
   PairFwdArgs A;
-  A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse;
+  A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb;
   A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
   // as many latent splits as there are latents to split (up to 8); the rest of the 8 waves take more queries
   int zs = 1;
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;
   A.qg = NWAVES / zs;
-#define ENF_CASE(DD, HH)                                                                   \
-  if (m.D == DD && m.H == HH) return m.bf16 ? launch_pair_fwd<DD, HH, true>(A, st) : launch_pair_fwd<DD, HH, false>(A, st);
+  const bool zfold = wz && wzb && (size_t)m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
+  if (zfold) {
+    A.qg = NWAVES;
+    int rc = enf_launch_wz(m, L, blob, lt, wz, wzb, st);
+    if (rc) return rc;
+  }
+#define ENF_CASE(DD, HH)                                                                                      \
+  if (m.D == DD && m.H == HH) {                                                                               \
+    if (zfold) return m.bf16 ? launch_pair_fwd<DD, HH, true, true>(A, st) : launch_pair_fwd<DD, HH, false, true>(A, st); \
+    return m.bf16 ? launch_pair_fwd<DD, HH, true, false>(A, st) : launch_pair_fwd<DD, HH, false, false>(A, st);         \
+  }
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   tail_consts<D, H, BF16>(cst, A.blob, A.L, tid);
   Pipe P;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
+  P.rs2 = P.rs;
   first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
   tail_forward<D, H, BF16, false, 1024>(o4, A.ybar + (size_t)qi * T::HD, nullptr, A.L, cst, P, ring, NO_STAGE, lane, quad);
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   tail_consts<D, H, BF16>(cst, A.blob, A.L, tid);
   Pipe P;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
+  P.rs2 = P.rs;
   first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
   tail_forward<D, H, BF16, true, T::ST_G4>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, lane, quad);

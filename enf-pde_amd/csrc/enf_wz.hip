@@ -1,0 +1,136 @@
+// enf_wz.hip -- K1b: per-latent fold of FiLM + the mixer's first Dense (z-fold forward path).
+//
+// Between the gamma/beta projection and the mixer's gelu there is no nonlinearity (ECA:112-122, ECA:17):
+//   v_h   = v0_zh (1 + gamma_h) + beta_h,   [gamma_h | beta_h] = n AGB_h + b            (FiLM, ECA:115-121)
+//   a5_h  = v_h AM + bm                                                                    (mixer Dense_0, ECA:17)
+// so for one latent z and head h
+//   a5_h  = n W_zh + c_zh,   W_zh = (Wgamma_h diag(v0_zh) + Wbeta_h) AM,
+//                            c_zh = (v0_zh (1 + bgamma_h) + bbeta_h) AM + bm
+// which turns two per-pair GEMMs (D x 2D and D x D) and the FiLM arithmetic into ONE D x D GEMM whose
+// matrix depends on the latent only.  This kernel builds W_zh directly in the pair kernel's packed
+// A-fragment order and c_zh as fp32 vectors.  2 D^3 FLOP per (latent, head): 8.6 GFLOP for 1024 latents,
+// against 2 TFLOP of per-pair work it feeds.
+//
+// One wave = one (latent, head, 32-row block of W).  The product runs "flipped" (gemm_tile_flip): rows of
+// W (the GEMM's input features i) play the role of activation columns, so the accumulator tile of
+// (i-tile, k-tile) holds, lane by lane, exactly the elements of that lane's A-fragment (k-tile, i-block):
+// the result is converted and stored 16 bytes per lane, lane-linear, no transpose.
+#include <hip/hip_runtime.h>
+#include "enf_layout.h"
+#include "enf_device.h"
+
+struct WzArgs {
+  const float* lt; const char* blob; EnfLayout L;
+  char* wz; float* wzb;
+  int BZ;
+};
+
+constexpr int WZ_WAVES = 4;
+
+template <int D, int H, bool BF16>
+__global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
+  constexpr int KB = D / 32, NT = D / 16;
+  constexpr int PB = D * D * (BF16 ? 2 : 4);                      // bytes of one packed D x D panel
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // the AM forward panel (B operand here)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, quad = lane >> 4;
+  {
+    const char* src = A.blob + A.L.am;
+    for (int o = tid * 16; o < PB; o += 64 * WZ_WAVES * 16)
+      *reinterpret_cast<f32x4*>(smem + o) = *reinterpret_cast<const f32x4*>(src + o);
+  }
+  __syncthreads();
+  auto G = [&](size_t off) { return reinterpret_cast<const float*>(A.blob + off); };
+  const float* agb = G(A.L.p_agb);
+  const int ltstride = enf_lt_stride(H, D);
+  const int ntask = A.BZ * H * KB;
+  for (int task = blockIdx.x * WZ_WAVES + wave; task < ntask; task += gridDim.x * WZ_WAVES) {
+    const int blk = task % KB, h = (task / KB) % H, bz = task / (KB * H);
+    const float* v0 = A.lt + (size_t)bz * ltstride + enf_lt_off_v0(H, D) + h * D;
+    // "activation" fragments: X[i][j] = Wgamma_h[i][j] v0[j], rows i = 16 (2 blk + a) + col as columns
+    Frags<BF16, KB> FX[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float* row = agb + (size_t)(16 * (2 * blk + a) + col) * (2 * H * D) + h * 2 * D;
+      f32x4 X[NT];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(row + 64 * (tj >> 1) + 16 * (tj & 1) + 4 * quad);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(v0 + 16 * tj + 4 * quad);
+        X[tj] = w * v;
+      }
+      make_frags<BF16, KB>(FX[a], X);
+    }
+    char* panel = A.wz + (size_t)(bz * H + h) * PB;
+    const float* wbmt = G(A.L.p_wbmt) + (size_t)h * D * D;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x4 af[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        af[a] = *reinterpret_cast<const f32x4*>(wbmt + (size_t)(16 * kt + col) * D + 16 * (2 * blk + a) + 4 * quad);
+        gemm_tile_flip<BF16, KB>(af[a], FX[a], smem, kt, lane);
+      }
+      if constexpr (BF16) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)af[j >> 2][j & 3];
+        *reinterpret_cast<bf16x8*>(panel + (((kt * KB + blk) * 64 + lane) << 4)) = o;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          *reinterpret_cast<f32x4*>(panel + (((kt * 2 * KB + 2 * blk + a) * 64 + lane) << 4)) = af[a];
+      }
+    }
+    if (blk == 0) {      // bias row: column 0 carries v0 (1 + bgamma_h); the product's row 0 is c_zh - cb_h
+      const float* opbg = G(A.L.p_opbg) + h * D;
+      const float* cb = G(A.L.p_cb) + h * D;
+      f32x4 X[NT];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(v0 + 16 * tj + 4 * quad);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(opbg + 16 * tj + 4 * quad);
+        X[tj] = col == 0 ? v * g : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      Frags<BF16, KB> FB;
+      make_frags<BF16, KB>(FB, X);
+      float* dst = A.wzb + (size_t)(bz * H + h) * D;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        f32x4 ab = {0.f, 0.f, 0.f, 0.f};
+        gemm_tile_flip<BF16, KB>(ab, FB, smem, kt, lane);
+        if (quad == 0) dst[16 * kt + col] = ab[0] + cb[16 * kt + col];
+      }
+    }
+  }
+}
+
+template <int D, int H, bool BF16>
+static int launch_wz(const WzArgs& A, hipStream_t st) {
+  constexpr int PB = D * D * (BF16 ? 2 : 4);
+  auto kern = enf_wz_kernel<D, H, BF16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PB) != hipSuccess)
+      return ENF_ELAUNCH;
+    attr_set = true;
+  }
+  const int ntask = A.BZ * H * (D / 32);
+  int grid = (ntask + WZ_WAVES - 1) / WZ_WAVES;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WZ_WAVES), PB, st, A);
+  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+}
+
+extern "C" int enf_launch_wz(const EnfDims& m, const EnfLayout& L, const char* blob, const float* lt, char* wz, float* wzb,
+                             hipStream_t st) {
+  WzArgs A;
+  A.lt = lt; A.blob = blob; A.L = L; A.wz = wz; A.wzb = wzb; A.BZ = m.B * m.Z;
+#define ENF_CASE(DD, HH)                                                                   \
+  if (m.D == DD && m.H == HH) return m.bf16 ? launch_wz<DD, HH, true>(A, st) : launch_wz<DD, HH, false>(A, st);
+  ENF_CASE(128, 2)
+  ENF_CASE(64, 2)
+  ENF_CASE(128, 1)
+  ENF_CASE(64, 1)
+#undef ENF_CASE
+  return ENF_EUNSUPPORTED;
+}

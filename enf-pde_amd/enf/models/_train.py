@@ -73,8 +73,10 @@ class _PairFunction(torch.autograd.Function):
         _lib.check(lib.enf_pack_pair(ctypes.byref(desc), arr, _ptr(blob), st))
         ybar = torch.empty((B, N, H * D), device=dev, dtype=torch.float32)
         lse = torch.empty((B, N, H), device=dev, dtype=torch.float32)
+        nscr = int(lib.enf_pair_scratch_bytes(ctypes.byref(desc)))
+        scratch = torch.empty(nscr, device=dev, dtype=torch.uint8) if nscr else None
         _lib.check(lib.enf_pair_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(lt_), _ptr(blob), _ptr(ybar),
-                                        _ptr(lse), st))
+                                        _ptr(lse), _ptr(scratch), nscr, st))
         ctx.model, ctx.xstride, ctx.dims = model, xstride, (B, N, Z)
         ctx.need_w = any(ctx.needs_input_grad[3:])
         ctx.save_for_backward(xb, lt_, blob, ybar, lse)

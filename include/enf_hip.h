@@ -160,14 +160,21 @@ enum { ENF_S_EQ = 0, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_D
 
 int enf_lt_layout(const EnfDesc* d, int* stride, int* off_u, int* off_v0, int* off_pose, int* off_wcoef, int* off_c);
 int enf_pack_pair(const EnfDesc* d, const float* const* pair_tensors, void* packed, void* stream);
-/* K2 alone: lt -> ybar (B,N,H*D), lse (B,N,H) */
+/* K2 alone: lt -> ybar (B,N,H*D), lse (B,N,H).  `scratch` (enf_pair_scratch_bytes; may be 0 -> NULL) holds the
+ * per-latent folded matrices of the large-N forward variant. */
+size_t enf_pair_scratch_bytes(const EnfDesc* d);
 int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
-                     float* ybar, float* lse, void* stream);
+                     float* ybar, float* lse, void* scratch, size_t scratch_bytes, void* stream);
 /* K3 alone: d ybar, delta[n,h] = d ybar . ybar, lse -> d lt (same layout as lt, overwritten);
  * `store` = NULL or ENF_NUM_STORE(H) device buffers of B*Z*N rows (see ENF_S_*). */
 int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
                       const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
                       void* stream);
+
+/* Forward pair-kernel variant: -1 = choose by problem size (default), 0 = latent-split, 1 = z-fold
+ * (DESIGN.md 5).  Also settable with ENF_ZFOLD=0/1 in the environment.  Affects enf_workspace_bytes /
+ * enf_pair_scratch_bytes: size buffers after setting it.  Process-wide; meant for tests and benchmarks. */
+void enf_set_zfold(int mode);
 
 #ifdef __cplusplus
 }

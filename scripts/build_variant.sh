@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build an experimental variant of libenf_hip.so:  scripts/build_variant.sh NAME "-DFLAG=.. -f.."
+# -> variants/libenf_NAME.so (git-ignored, travels to the GPU box); select with ENF_HIP_LIB=variants/libenf_NAME.so
+set -e
+cd "$(dirname "$0")/.."
+NAME=$1; FLAGS=$2
+mkdir -p variants build_variants/$NAME
+SRC=enf-pde_amd/csrc
+for f in enf_api enf_pack enf_wz enf_pair_fwd enf_pair_bwd enf_tail enf_debug; do
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unknown-pragmas $FLAGS -c $SRC/$f.hip -o build_variants/$NAME/$f.o ) &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build_variants/$NAME/*.o -o variants/libenf_$NAME.so
+echo built variants/libenf_$NAME.so

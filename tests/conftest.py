@@ -18,3 +18,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["latent_split", "z_fold"])
+def pair_variant(request):
+    """Runs a test under both forward pair-kernel variants (enf_set_zfold, include/enf_hip.h)."""
+    from enf_pde_amd import _lib
+    lib = _lib.load()
+    lib.enf_set_zfold(1 if request.param == "z_fold" else 0)
+    yield request.param
+    lib.enf_set_zfold(-1)

@@ -6,7 +6,7 @@ import torch
 from oracle import enf_ref_np as R
 from tests.helpers import make_cfg, make_inputs, build_nef
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pair_variant")]
 
 # tolerances on max|err| / max|ref| : fp32 mode = exact-fp32 MFMA chain; bf16 mode = bf16 operands
 TOL = {"f32": 2e-5, "bf16": 3e-2}
@@ -61,3 +61,27 @@ def test_forward_no_window(cuda):
     cfg = make_cfg("rel_pos", use_window=False, freq=(0.5, 0.5))
     err, _ = run_case(cuda, cfg, B=2, N=64, Z=8, precision="f32")
     assert err < TOL["f32"]
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_variants_agree_at_full_size(cuda, precision):
+    """BASELINE.json's full decode shape (16 signals x 64^2 queries x 64 latents) is too large for the oracle:
+    the two independent forward variants (latent-split, z-fold with per-latent folded matrices) must agree."""
+    from enf_pde_amd import _lib
+    cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
+    prm = R.init_params(11, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 16, 4096, 64, 12)
+    nef = build_nef(cfg, precision)
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    outs = []
+    lib = _lib.load()
+    try:
+        for mode in (0, 1):
+            lib.enf_set_zfold(mode)
+            outs.append(nef.apply(params, t(x), t(p), t(a), t(s)))
+    finally:
+        lib.enf_set_zfold(-1)
+    ref, got = outs
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert torch.isfinite(got).all() and err < (2e-5 if precision == "f32" else 3e-2), err

@@ -10,7 +10,7 @@ from oracle import enf_ref_np as R
 from tests.helpers import make_cfg, make_inputs, build_nef
 from tests.golden.make_golden import CASES
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pair_variant")]
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 TOL_OUT = {"f32": 2e-5, "bf16": 3e-2}      # max|err| / max|ref|
 TOL_GRAD = {"f32": 2e-4, "bf16": 6e-2}     # relative L2
