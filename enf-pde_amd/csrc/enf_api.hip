@@ -9,7 +9,7 @@ int enf_launch_prologue(const EnfDims&, const EnfLayout&, const char*, const flo
 int enf_launch_prologue_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, const float*,
                             const float*, const float*, float*, float*, float*, hipStream_t);
 int enf_launch_pair_fwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, float*, float*,
-                        char*, float*, hipStream_t);
+                        char*, float*, char*, hipStream_t);
 int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, const float*,
                         const float*, const float*, float*, void* const*, hipStream_t);
 int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
@@ -84,7 +84,8 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
   const bool zf = enf_use_zfold(m);
   float* ls = lse ? lse : F(W.lse);
   if ((stages & ENF_STAGE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
-  if ((stages & ENF_STAGE_PAIR) && (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr, st))) return rc;
+  if ((stages & ENF_STAGE_PAIR) && (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
+                                                             zf ? ws + W.wzu : nullptr, st))) return rc;
   if ((stages & ENF_STAGE_TAIL) && (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, nullptr, 0, st))) return rc;
   return ENF_OK;
 }
@@ -147,7 +148,8 @@ extern "C" size_t enf_pair_scratch_bytes(const EnfDesc* d) {
   if (enf_check_desc(d)) return 0;
   const EnfDims m = enf_dims(d);
   if (!enf_use_zfold(m)) return 0;
-  return enf_align((size_t)m.B * m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16)) + sizeof(float) * (size_t)m.B * m.Z * m.HD;
+  return enf_align((size_t)m.B * m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16)) +
+         enf_align(sizeof(float) * (size_t)m.B * m.Z * m.HD) + (size_t)m.B * m.Z * enf_wzu_bytes(m.H, m.D);
 }
 
 extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
@@ -160,7 +162,9 @@ extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstr
   if (need && (!scratch || scratch_bytes < need)) return ENF_EWORKSPACE;
   char* wz = need ? (char*)scratch : nullptr;
   float* wzb = need ? reinterpret_cast<float*>(wz + enf_align((size_t)m.B * m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16))) : nullptr;
-  return enf_launch_pair_fwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, ybar, lse, wz, wzb, (hipStream_t)stream);
+  char* wzu = need ? reinterpret_cast<char*>(wzb) + enf_align(sizeof(float) * (size_t)m.B * m.Z * m.HD) : nullptr;
+  return enf_launch_pair_fwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, ybar, lse, wz, wzb, wzu,
+                             (hipStream_t)stream);
 }
 
 extern "C" int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,

@@ -50,11 +50,37 @@ DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
   }
 }
 
+#ifndef ENF_GELU_PK
+#define ENF_GELU_PK 1
+#endif
+#ifndef ENF_RELU_ASM
+#define ENF_RELU_ASM 1
+#endif
 #include "enf_gemm_asm.h"
 #ifndef ENF_ASM_GEMM
 #define ENF_ASM_GEMM 1
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// relu on fragments.  bf16: as 16-bit integers negative floats are negative, so one v_pk_max_i16 with 0
+// clamps two values (-0 -> +0); fp32: v_max per value.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool BF16, int KB> DEV void relu_frags(Frags<BF16, KB>& F) {
+  if constexpr (BF16) {
+#pragma unroll
+    for (int blk = 0; blk < KB; ++blk) {
+      u32x4 w = __builtin_bit_cast(u32x4, F.f[blk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm("v_pk_max_i16 %0, %1, 0" : "=v"(w[i]) : "v"(w[i]));
+      F.f[blk] = __builtin_bit_cast(bf16x8, w);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2 * KB; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) F.f[t][i] = fmaxf(F.f[t][i], 0.f);
+  }
+}
 
 // acc[mt] += W^T[16 mt .., :] X for MTS out-tiles whose fragments start at `lds`.
 // Panel order (enf_pack.hip): bf16 [mt][blk][lane] x 16 B; fp32 [mt][in-tile][lane] x 16 B.
@@ -126,6 +152,42 @@ DEV float gelu_f(float x) {
   const float c2 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2*sqrt(2/pi)*log2(e)
   const float u = x * (c2 + (c2 * 0.044715f) * x * x);
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+}
+// the same on whole tiles, two values per instruction (v_pk_mul/fma/add_f32; exp and rcp stay scalar)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEV f32x2 gelu_f2(f32x2 x) {
+  const float c2 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  const f32x2 u = x * (x * x * (c2 * 0.044715f) + c2);
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(u[0]);
+  e[1] = __builtin_amdgcn_exp2f(u[1]);
+  e = e + 1.0f;
+  f32x2 s;
+  s[0] = __builtin_amdgcn_rcpf(e[0]);
+  s[1] = __builtin_amdgcn_rcpf(e[1]);
+  return x * s;
+}
+template <int NT> DEV void gelu_tiles(f32x4 (&X)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#if ENF_GELU_PK
+    const f32x2 lo = gelu_f2(f32x2{X[t][0], X[t][1]}), hi = gelu_f2(f32x2{X[t][2], X[t][3]});
+    X[t] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[t][i] = gelu_f(X[t][i]);
+#endif
+  }
+}
+// relu without the canonicalising second v_max that fmaxf(x, 0) costs (MFMA results are never signalling)
+DEV float relu_f(float x) {
+#if ENF_RELU_ASM
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+#else
+  return fmaxf(x, 0.f);
+#endif
 }
 // d/dx of the above: s + x s (1-s) 2c(1+3*0.044715x^2),  s = sigmoid(2c(x+0.044715x^3))
 DEV float gelu_grad_f(float x) {

@@ -157,6 +157,8 @@ inline bool enf_use_zfold(const EnfDims& m) {
   return (long long)((m.N + 127) / 128) * m.B >= 192;
 }
 
+ENF_HD inline size_t enf_wzu_bytes(int H, int D) { return (size_t)(D / 32) * 4 * H * 16; }
+
 struct EnfWorkspace {
   size_t lt;        // B*Z*lt_stride floats: latent table
   size_t an;        // B*Z*(D + D + 2) floats: stem output, a_norm, LN mean/rstd (prologue backward)
@@ -169,6 +171,7 @@ struct EnfWorkspace {
   size_t dlt;       // B*Z*lt_stride floats: gradient of the latent table (backward)
   size_t wz;        // B*Z*H packed D x D panels: per-latent mixer-input matrices (z-fold forward only)
   size_t wzb;       // B*Z*H*D floats: their bias vectors
+  size_t wzu;       // B*Z x (D/32 * 4 * H) x 16 B: the logit vectors u_zh as bf16 A-operand rows (z-fold, bf16 mode)
   size_t total;
 };
 
@@ -190,6 +193,7 @@ inline EnfWorkspace enf_workspace(const EnfDims& m) {
   const bool zf = enf_use_zfold(m);
   W.wz = take(zf ? BZ * m.H * enf_panel_bytes(m.D, m.D, m.bf16) : 0);
   W.wzb = take(zf ? f * BZ * m.HD : 0);
+  W.wzu = take(zf ? BZ * enf_wzu_bytes(m.H, m.D) : 0);
   W.total = o;
   return W;
 }

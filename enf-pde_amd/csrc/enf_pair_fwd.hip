@@ -26,7 +26,7 @@ struct PairFwdArgs {
   const float* x; long long x_bstride;
   const float* lt; const char* blob; EnfLayout L;
   float* ybar; float* lse;
-  const char* wz; const float* wzb;       // z-fold only: per-latent mixer-input panels / biases (enf_wz.hip)
+  const char* wz; const float* wzb; const char* wzu;   // z-fold only: per-latent mixer-input panels / biases (enf_wz.hip)
   int B, N, Z, dx, inv, use_window, qg;   // qg: query groups per workgroup (1,2,4,8); ZS = 8/qg
 };
 
@@ -46,8 +46,11 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #define STAMP(k) do {} while (0)
 #endif
 
+#ifndef ENF_ABL_SAMEPANEL
+#define ENF_ABL_SAMEPANEL 0
+#endif
 #ifndef ENF_ANTIPHASE
-#define ENF_ANTIPHASE true
+#define ENF_ANTIPHASE false
 #endif
 
 template <int D, int H, bool BF16> struct PairSmem {
@@ -117,12 +120,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
     const float* ltrow = A.lt + ((size_t)b * A.Z + (active ? z : A.Z - 1)) * ltstride;
     STAMP(0);
     // per-latent vectors u | v0 -> wave-private LDS
-    if constexpr (ZFOLD) {      // u from the latent table, c_zh from the fold kernel
+    if constexpr (ZFOLD) {      // u (bf16: as A-operand rows) and c_zh from the fold kernel
       const float* czrow = A.wzb + ((size_t)b * A.Z + z) * (H * D);
 #pragma unroll
       for (int i = lane * 4; i < H * D; i += 256) {
-        *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+        if constexpr (!BF16) *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
         *reinterpret_cast<f32x4*>(zv + H * D + i) = *reinterpret_cast<const f32x4*>(czrow + i);
+      }
+      if constexpr (BF16) {
+        if (lane < KB * 4 * H)
+          *reinterpret_cast<f32x4*>(zv + lane * 4) =
+              *reinterpret_cast<const f32x4*>(A.wzu + ((size_t)b * A.Z + z) * enf_wzu_bytes(H, D) + lane * 16);
       }
     } else {
 #pragma unroll
@@ -148,6 +156,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
       STAMP(1);
       panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pQ1, pV1, active, lane);
       STAMP(2);
+      if constexpr (ZFOLD && BF16) {
+        // logits on the matrix pipe: rows 0..H-1 of the A operand are u_zh (bf16, packed by enf_wz_kernel),
+        // B = relu(a1) fragments; lane (col, quad 0) register h then holds h1 . u_h of query `col`
+        static_assert(H <= 4, "logit rows live in one quad");
+        make_frags<BF16, KB>(F, acc);
+        relu_frags<BF16, KB>(F);
+        f32x4 lg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < KB; ++blk) {
+          bf16x8 ua = __builtin_bit_cast(bf16x8, f32x4{0.f, 0.f, 0.f, 0.f});
+          if (col < H) ua = *reinterpret_cast<const bf16x8*>(zv + ((blk * 4 + quad) * H + col) * 4);
+          lg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua, F.f[blk], lg, 0, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) logit[h] = __shfl(lg[h], col, 64) + ltrow[enf_lt_off_c(H, D) + h] + win;
+      } else
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float s = 0.f;
@@ -155,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
         for (int t = 0; t < NT; ++t) {
           const f32x4 u = rowvec(zv + h * D, t, quad);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s = fmaf(fmaxf(acc[t][i], 0.f), u[i], s);
+          for (int i = 0; i < 4; ++i) s = fmaf(relu_f(acc[t][i]), u[i], s);
         }
         logit[h] = xquad_sum(s) + ltrow[enf_lt_off_c(H, D) + h] + win;
       }
@@ -170,21 +194,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
       STAMP(4);
       panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pV1, pF, active, lane);
       STAMP(5);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = fmaxf(acc[t][i], 0.f);
       make_frags<BF16, KB>(F, acc);
+      relu_frags<BF16, KB>(F);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bf, t, quad);
       STAMP(6);
-      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(z * H * PANEL_DD), active, lane);
+      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(ENF_ABL_SAMEPANEL ? 0 : z * H * PANEL_DD), active, lane);
       else panel_gemm<KB, NT, BF16, ST_GB>(acc, F, P, ring, pF, pGB, active, lane);
       STAMP(7);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = gelu_f(acc[t][i]);
+      gelu_tiles<NT>(acc);
       float mu, rstd;
       ln_stats<NT>(acc, mu, rstd);
       const float nmr = -mu * rstd;
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
     for (int h = 0; h < H; ++h) {
       f32x4 v[NT];
       if constexpr (ZFOLD) {
-        const unsigned wzh = STAGE_RS2 | (unsigned)((z * H + h) * PANEL_DD);
+        const unsigned wzh = STAGE_RS2 | (unsigned)(((ENF_ABL_SAMEPANEL ? 0 : z) * H + h) * PANEL_DD);
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = rowvec(zv + H * D + h * D, t, quad);
         STAMP(10 + 4 * h);
@@ -219,10 +237,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
         else panel_gemm<KB, NT, BF16, ST_DD>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane);
       }
       STAMP(11 + 4 * h);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[t][i] = gelu_f(v[t][i]);
+      gelu_tiles<NT>(v);
       float mu, rstd;
       ln_stats<NT>(v, mu, rstd);
       if (active) {
@@ -337,22 +352,23 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
-extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, hipStream_t);
+extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, hipStream_t);
 
 // wz / wzb: scratch for the z-fold variant (enf_workspace: W.wz, W.wzb), or NULL for the latent-split variant
 extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
-                                   const float* lt, float* ybar, float* lse, char* wz, float* wzb, hipStream_t st) {
+                                   const float* lt, float* ybar, float* lse, char* wz, float* wzb, char* wzu,
+                                   hipStream_t st) {
   PairFwdArgs A;
-  A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb;
+  A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu;
   A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
   // as many latent splits as there are latents to split (up to 8); the rest of the 8 waves take more queries
   int zs = 1;
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;
   A.qg = NWAVES / zs;
-  const bool zfold = wz && wzb && (size_t)m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
+  const bool zfold = wz && wzb && wzu && (size_t)m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
   if (zfold) {
     A.qg = NWAVES;
-    int rc = enf_launch_wz(m, L, blob, lt, wz, wzb, st);
+    int rc = enf_launch_wz(m, L, blob, lt, wz, wzb, wzu, st);
     if (rc) return rc;
   }
 #define ENF_CASE(DD, HH)                                                                                      \

@@ -21,7 +21,7 @@
 
 struct WzArgs {
   const float* lt; const char* blob; EnfLayout L;
-  char* wz; float* wzb;
+  char* wz; float* wzb; char* wzu;
   int BZ;
 };
 
@@ -81,6 +81,19 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
           *reinterpret_cast<f32x4*>(panel + (((kt * 2 * KB + 2 * blk + a) * 64 + lane) << 4)) = af[a];
       }
     }
+    if (BF16 && blk == 0 && h == 0) {
+      // logit vectors as the rows of a bf16 A operand: entry ((kb*4 + kq)*H + hh) = the 8 k-values lane
+      // (m = hh, kq) of block kb feeds v_mfma_f32_16x16x32_bf16 (rows m >= H are zero and not stored)
+      if (lane < KB * 4 * H) {
+        const int hh = lane % H, kq = (lane / H) % 4, kb = lane / (4 * H);
+        const float* u = A.lt + (size_t)bz * ltstride + enf_lt_off_u(H, D) + hh * D + 32 * kb + 4 * kq;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(u), hi = *reinterpret_cast<const f32x4*>(u + 16);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+        *reinterpret_cast<bf16x8*>(A.wzu + (size_t)bz * enf_wzu_bytes(H, D) + lane * 16) = o;
+      }
+    }
     if (blk == 0) {      // bias row: column 0 carries v0 (1 + bgamma_h); the product's row 0 is c_zh - cb_h
       const float* opbg = G(A.L.p_opbg) + h * D;
       const float* cb = G(A.L.p_cb) + h * D;
@@ -122,9 +135,9 @@ static int launch_wz(const WzArgs& A, hipStream_t st) {
 }
 
 extern "C" int enf_launch_wz(const EnfDims& m, const EnfLayout& L, const char* blob, const float* lt, char* wz, float* wzb,
-                             hipStream_t st) {
+                             char* wzu, hipStream_t st) {
   WzArgs A;
-  A.lt = lt; A.blob = blob; A.L = L; A.wz = wz; A.wzb = wzb; A.BZ = m.B * m.Z;
+  A.lt = lt; A.blob = blob; A.L = L; A.wz = wz; A.wzb = wzb; A.wzu = wzu; A.BZ = m.B * m.Z;
 #define ENF_CASE(DD, HH)                                                                   \
   if (m.D == DD && m.H == HH) return m.bf16 ? launch_wz<DD, HH, true>(A, st) : launch_wz<DD, HH, false>(A, st);
   ENF_CASE(128, 2)

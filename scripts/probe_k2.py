@@ -4,5 +4,5 @@ import bench
 dev = torch.device("cuda:0")
 nef, params, lat0, lrs, masks = bench.build(dev, "bf16")
 coords, img = bench.synth_fields(bench.B_PER_GPU, 100, dev)
-r = bench.roofline_leg(nef, params, coords, dev, iters=10)
+r = bench.roofline_leg(nef, params, coords, dev, iters=40)
 print(sys.argv[1] if len(sys.argv) > 1 else "", "K2 launch_ms", r["launch_ms"], "frac", r["frac"])
