@@ -9,7 +9,7 @@ int enf_launch_prologue(const EnfDims&, const EnfLayout&, const char*, const flo
 int enf_launch_prologue_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, const float*,
                             const float*, const float*, float*, float*, float*, hipStream_t);
 int enf_launch_pair_fwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, float*, float*,
-                        char*, float*, char*, hipStream_t);
+                        char*, float*, char*, int, int, hipStream_t);
 int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, const float*,
                         const float*, const float*, float*, void* const*, hipStream_t);
 int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
@@ -84,8 +84,10 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
   const bool zf = enf_use_zfold(m);
   float* ls = lse ? lse : F(W.lse);
   if ((stages & ENF_STAGE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
-  if ((stages & ENF_STAGE_PAIR) && (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
-                                                             zf ? ws + W.wzu : nullptr, st))) return rc;
+  if ((stages & (ENF_STAGE_PAIR | ENF_STAGE_FOLD)) &&
+      (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
+                                zf ? ws + W.wzu : nullptr, (stages & ENF_STAGE_FOLD) != 0, (stages & ENF_STAGE_PAIR) != 0, st)))
+    return rc;
   if ((stages & ENF_STAGE_TAIL) && (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, nullptr, 0, st))) return rc;
   return ENF_OK;
 }
@@ -94,7 +96,7 @@ extern "C" int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, 
                            const float* sigma, const void* packed, float* out, float* ybar, float* lse, void* workspace,
                            size_t workspace_bytes, void* stream) {
   return enf_forward_stages(d, x, x_bstride, p, a, sigma, packed, out, ybar, lse, workspace, workspace_bytes,
-                            ENF_STAGE_PROLOGUE | ENF_STAGE_PAIR | ENF_STAGE_TAIL, stream);
+                            ENF_STAGE_PROLOGUE | ENF_STAGE_FOLD | ENF_STAGE_PAIR | ENF_STAGE_TAIL, stream);
 }
 
 extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
@@ -163,7 +165,7 @@ extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstr
   char* wz = need ? (char*)scratch : nullptr;
   float* wzb = need ? reinterpret_cast<float*>(wz + enf_align((size_t)m.B * m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16))) : nullptr;
   char* wzu = need ? reinterpret_cast<char*>(wzb) + enf_align(sizeof(float) * (size_t)m.B * m.Z * m.HD) : nullptr;
-  return enf_launch_pair_fwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, ybar, lse, wz, wzb, wzu,
+  return enf_launch_pair_fwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, ybar, lse, wz, wzb, wzu, 1, 1,
                              (hipStream_t)stream);
 }
 

@@ -53,6 +53,9 @@ DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
 #ifndef ENF_GELU_PK
 #define ENF_GELU_PK 1
 #endif
+#ifndef ENF_GELU_POLY
+#define ENF_GELU_POLY 0
+#endif
 #ifndef ENF_RELU_ASM
 #define ENF_RELU_ASM 1
 #endif
@@ -61,6 +64,21 @@ DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
 #define ENF_ASM_GEMM 1
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// A tile array parked in half the registers between two uses (bf16 mode: the same packing as a fragment
+// set; fp32 mode: kept as is).  park() / unpark(tile): one cvt_pk per two values, one shift/and per value.
+template <bool BF16, int NT> struct Parked {
+  Frags<BF16, NT / 2> p;
+  DEV void park(const f32x4 (&X)[NT]) { make_frags<BF16, NT / 2>(p, X); }
+  DEV f32x4 get(int t) const {
+    if constexpr (BF16) {
+      const int blk = t >> 1, o = (t & 1) * 4;
+      return f32x4{(float)p.f[blk][o], (float)p.f[blk][o + 1], (float)p.f[blk][o + 2], (float)p.f[blk][o + 3]};
+    } else {
+      return p.f[t];
+    }
+  }
+};
 
 // relu on fragments.  bf16: as 16-bit integers negative floats are negative, so one v_pk_max_i16 with 0
 // clamps two values (-0 -> +0); fp32: v_max per value.
@@ -167,9 +185,32 @@ DEV f32x2 gelu_f2(f32x2 x) {
   s[1] = __builtin_amdgcn_rcpf(e[1]);
   return x * s;
 }
-template <int NT> DEV void gelu_tiles(f32x4 (&X)[NT]) {
+// Transcendental-free alternative (off: ENF_GELU_POLY=0).  gelu_tanh(x) = x (0.5 + f(x)), f = 0.5 tanh(..) is odd
+// and saturates: f(x) ~ xc Q(xc^2), xc = clamp(x, -4, 4), Q of degree 6 (Lawson/minimax fit, max |error| 2.8e-4).
+// Measured on gfx950 (scripts/ubench/valu_rates.hip, per SIMD with two waves, v_fma_f32 = 1): v_pk_fma/mul_f32
+// 1.73, v_exp/v_rcp/v_sin 2.5, v_med3 1.33 -- so 2 med3 + 9 packed ops per value pair cost what 4 transcendentals
+// + 5 packed ops do: no gain, and the exact form is kept.
+DEV f32x2 gelu_poly2(f32x2 x) {
+  f32x2 xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f);
+  xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f);
+  const f32x2 s = xc * xc;
+  f32x2 q = s * 2.394300707e-08f + -1.664713792e-06f;
+  q = q * s + 4.940474534e-05f;
+  q = q * s + -8.289572461e-04f;
+  q = q * s + 8.840011712e-03f;
+  q = q * s + -6.464239978e-02f;
+  q = q * s + 3.977454025e-01f;
+  return x * (xc * q + 0.5f);
+}
+template <int NT, bool FAST = false> DEV void gelu_tiles(f32x4 (&X)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if constexpr (FAST && ENF_GELU_POLY) {
+      const f32x2 lo = gelu_poly2(f32x2{X[t][0], X[t][1]}), hi = gelu_poly2(f32x2{X[t][2], X[t][3]});
+      X[t] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+      continue;
+    }
 #if ENF_GELU_PK
     const f32x2 lo = gelu_f2(f32x2{X[t][0], X[t][1]}), hi = gelu_f2(f32x2{X[t][2], X[t][3]});
     X[t] = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -296,12 +337,22 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
     if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     const char* slot = ring + P.cur * STAGE_MAX;
-    if constexpr (TRANS) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, slot, lane);
+    if constexpr (TRANS && BF16 && ENF_ASM_GEMM && GemmStageAsm<KBIN, C::MTS>::available) {
+      // one fragment read feeds both products (hand-scheduled stage, enf_gemm_asm.h)
+      f32x4 af[C::MTS];
 #pragma unroll
-    for (int mt = 0; mt < C::MTS; ++mt) {
-      f32x4 af = flip_init(sp * C::MTS + mt);
-      gemm_tile_flip<BF16, KBIN>(af, F, slot, mt, lane);
-      flip(sp * C::MTS + mt, af);
+      for (int mt = 0; mt < C::MTS; ++mt) af[mt] = flip_init(sp * C::MTS + mt);
+      GemmStageAsm<KBIN, C::MTS>::run_both(&acc[sp * C::MTS], af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
+#pragma unroll
+      for (int mt = 0; mt < C::MTS; ++mt) flip(sp * C::MTS + mt, af[mt]);
+    } else {
+      if constexpr (TRANS) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, slot, lane);
+#pragma unroll
+      for (int mt = 0; mt < C::MTS; ++mt) {
+        f32x4 af = flip_init(sp * C::MTS + mt);
+        gemm_tile_flip<BF16, KBIN>(af, F, slot, mt, lane);
+        flip(sp * C::MTS + mt, af);
+      }
     }
     stage_close(P);
   }

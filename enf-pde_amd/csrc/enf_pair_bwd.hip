@@ -30,6 +30,21 @@ struct PairBwdArgs {
   int B, N, Z, dx, inv, use_window, nsplit;
 };
 
+// Debug build only (-DENF_STAMPS): s_memtime stamps of the first tiles of one workgroup (scripts/stamps_k3.py)
+#ifdef ENF_STAMPS
+__device__ unsigned long long enf_stamps_bwd[8 * 4 * 24];
+#define BSTAMP(k)                                                                                             \
+  do {                                                                                                        \
+    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && ti < 4)                                            \
+      enf_stamps_bwd[(wave * 4 + ti) * 24 + (k)] = __builtin_amdgcn_s_memtime();                              \
+  } while (0)
+extern "C" int enf_debug_read_stamps_bwd(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(enf_stamps_bwd), sizeof(enf_stamps_bwd)) == hipSuccess ? 0 : -1;
+}
+#else
+#define BSTAMP(k) do {} while (0)
+#endif
+
 // one row of a materialised activation / delta = this lane's share of a fragment set
 template <bool BF16, int KB>
 DEV void store_frags(void* base, size_t row, int D, const Frags<BF16, KB>& F, int quad) {
@@ -85,7 +100,21 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
     f32x4 t[MTS];
 #pragma unroll
     for (int j = 0; j < MTS; ++j) t[j] = rowvec(bias, sp * MTS + j, quad);
-    gemm_stage<BF16, KB, MTS>(t, F, slot, lane);
+    constexpr bool ASM = BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS>::available && MTS == 8;
+    if constexpr (ASM) {
+      // transposed product of all 8 tiles + flipped product of the 4 gamma tiles {0,1,4,5} from one fragment read
+      f32x4 af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bc = 1.0f + bias[16 * (sp * MTS + 4 * (j >> 1) + (j & 1)) + col];
+        af[j] = f32x4{bc, bc, bc, bc};
+      }
+      GemmStageAsm<KB, MTS>::run_gb(t, af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) opgf[2 * (sp * (MTS / 4) + (j >> 1)) + (j & 1)] = af[j];
+    } else {
+      gemm_stage<BF16, KB, MTS>(t, F, slot, lane);
+    }
 #pragma unroll
     for (int g = 0; g < MTS / 4; ++g) {
 #pragma unroll
@@ -94,10 +123,12 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
         const f32x4 v0 = rowvec(v0vec, tile, quad);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[tile][i] = fmaf(v0[i], 1.0f + t[4 * g + e][i], t[4 * g + 2 + e][i]);
-        const float bc = 1.0f + bias[16 * (sp * MTS + 4 * g + e) + col];      // per-column bias of the flipped tile
-        f32x4 af = {bc, bc, bc, bc};
-        gemm_tile_flip<BF16, KB>(af, F, slot, 4 * g + e, lane);
-        opgf[tile] = af;
+        if constexpr (!ASM) {
+          const float bc = 1.0f + bias[16 * (sp * MTS + 4 * g + e) + col];      // per-column bias of the flipped tile
+          f32x4 af = {bc, bc, bc, bc};
+          gemm_tile_flip<BF16, KB>(af, F, slot, 4 * g + e, lane);
+          opgf[tile] = af;
+        }
       }
     }
     stage_wait();
@@ -253,6 +284,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     const size_t srow = (size_t)bzc * A.N + n;        // row of the materialised activations (STORE)
     const bool swrite = STORE && nvalid && active;
 
+    BSTAMP(0);
     // ---------------- q-forward: logits -> attention probabilities
     float att[H], dlogit[H];
     Frags<BF16, KB> F;
@@ -276,6 +308,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         att[h] = __expf(lg - A.lse[qrow * H + h]);
       }
     }
+    BSTAMP(1);
     // ---------------- v-forward to the normalised f
     unsigned relu_mask = 0u;             // bit (4t + i): a2[t][i] > 0
     f32x4 a3[NT], nh[NT];
@@ -312,6 +345,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, nh);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_NH], srow, D, F, quad);
     }
+    BSTAMP(2);
     f32x4 dnh[NT];                       // d n^ accumulated over heads
 #pragma unroll
     for (int t = 0; t < NT; ++t) dnh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -321,6 +355,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 v[NT], opgf[NT];
       gb_panel_flip<D, BF16, ST_DD>(v, opgf, F, P, ring, pGB + h * PANEL_GB, pM, c_bgb + 2 * h * D, zv + H * D + h * D,
                                     lane, col, quad);
+      BSTAMP(3 + 6 * h);
       f32x4 a5[NT];
       {
         Frags<BF16, KB> FV;
@@ -330,6 +365,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int t = 0; t < NT; ++t) a5[t] = rowvec(c_bm, t, quad);
         panel_gemm<KB, NT, BF16, ST_DD>(a5, FV, P, ring, pM, gM, true, lane);
       }
+      BSTAMP(4 + 6 * h);
       // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
       float mu2, r2;
 #pragma unroll
@@ -367,6 +403,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * gelu_grad_f(a5[t][i]);   // d a5
+      BSTAMP(5 + 6 * h);
       // d v = AM d a5 (transposed, feeds d gamma / d beta) and its flipped twin:
       // d v0[d] += sum_n dv[n][d] (1 + gamma[n][d])
       {
@@ -381,6 +418,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
               dV0[h][mt] += af[0] * opgf[mt][0] + af[1] * opgf[mt][1] + af[2] * opgf[mt][2] + af[3] * opgf[mt][3];
             });                                                                                               // v <- d v
       }
+      BSTAMP(6 + 6 * h);
       // FiLM backward: d gamma = d v * v0; d beta = d v.
       // B operand of the [g g b b]-ordered panel: block 2m = d gamma (tiles 2m, 2m+1), block 2m+1 = d beta
       Frags<BF16, 2 * KB> FG;
@@ -404,6 +442,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           FG.f[4 * m + 2] = v[2 * m]; FG.f[4 * m + 3] = v[2 * m + 1];
         }
       }
+      BSTAMP(7 + 6 * h);
       if (swrite) {
         Frags<BF16, KB> Fg, Fb;
 #pragma unroll
@@ -418,6 +457,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       else panel_gemm<2 * KB, NT, BF16, ST_DD>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, lane);
     }
 
+    BSTAMP(15);
     // ---------------- LN / gelu backward -> d a3 -> AF -> relu -> W1v -> d E_v -> d t_v -> d inv
     float dinv[4] = {0.f, 0.f, 0.f, 0.f};
     {
@@ -456,6 +496,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       gemm_stage<BF16, D / 64, 1>(di, FT, gcv, lane);
       if (quad == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
     }
+    BSTAMP(16);
     // ---------------- q-branch: recompute a1 (transposed, for the relu mask of d h1) and its flipped
     // twin h1f (rows = queries) for d u[f] += sum_n dlogit[n] h1f[n][f]
     {
@@ -507,6 +548,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       gemm_stage<BF16, D / 64, 1>(di, FT, gcq, lane);
       if (quad == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
     }
+    BSTAMP(17);
     // ---------------- per-latent scalars (each column is counted once: quad 0)
     if (quad == 0) {
       float dwin = 0.f;

@@ -46,6 +46,9 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #define STAMP(k) do {} while (0)
 #endif
 
+#ifndef ENF_ZFOLD_WAVES
+#define ENF_ZFOLD_WAVES 8
+#endif
 #ifndef ENF_ABL_SAMEPANEL
 #define ENF_ABL_SAMEPANEL 0
 #endif
@@ -53,13 +56,18 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #define ENF_ANTIPHASE false
 #endif
 
-template <int D, int H, bool BF16> struct PairSmem {
+// waves per workgroup: the z-fold variant runs TWO independent 4-wave workgroups per CU (one wave of each
+// per SIMD) so that the SIMD-mates never meet at a barrier: while one computes its MFMA stage the other
+// keeps the vector ALU busy (8-wave lockstep measured 2 V + M per stage, M = the younger wave's MFMAs).
+template <bool ZFOLD> struct PairWaves { static constexpr int NW = ZFOLD && ENF_ZFOLD_WAVES == 4 ? 4 : NWAVES; };
+
+template <int D, int H, bool BF16, int NW> struct PairSmem {
   static constexpr int RING = 0;                                   // 2 slots
   static constexpr int CONSTS = RING + 2 * STAGE_MAX;              // bq1 bv1 bf bm (D each) | bgb (2HD) | acq acv (2D each)
   static constexpr int N_CONST = 4 * D + 2 * H * D + 4 * D;
   static constexpr int ZVEC = CONSTS + 4 * N_CONST;                // NWAVES x 2*H*D floats
-  static constexpr int XCH = ZVEC + 4 * NWAVES * 2 * H * D;        // NWAVES x H x 3 x 16 floats
-  static constexpr int TOTAL = XCH + 4 * NWAVES * H * 3 * 16;
+  static constexpr int XCH = ZVEC + 4 * NW * 2 * H * D;            // NW x H x 3 x 16 floats
+  static constexpr int TOTAL = XCH + 4 * NW * H * 3 * 16;
   static constexpr int YBYTES = H * (D / 16) * 4 * 64 * 4;         // one wave's Y in [reg][lane] order
   static_assert(4 * YBYTES <= 2 * STAGE_MAX, "combine buffer must fit in the ring");
 };
@@ -68,9 +76,10 @@ template <int D, int H, bool BF16> struct PairSmem {
 // and the mixer's first Dense are ONE D x D GEMM with the per-latent matrix W_zh of enf_wz.hip:
 //   a5_h = W_zh^T n + c_zh      (5 D x D GEMMs per pair instead of 9 D x D equivalents)
 template <int D, int H, bool BF16, bool ZFOLD>
-__global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A) {
+__global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_kernel(PairFwdArgs A) {
   using Cfg = PairCfg<D, BF16>;
-  using SM = PairSmem<D, H, BF16>;
+  constexpr int NW = PairWaves<ZFOLD>::NW, NTH = 64 * NW;
+  using SM = PairSmem<D, H, BF16, NW>;
   constexpr int KB = Cfg::KB, NT = Cfg::NT;
   constexpr int ST_DD = Cfg::DD::STAGE, ST_GB = Cfg::GB::STAGE, PANEL_GB = Cfg::GB::BYTES, PANEL_DD = Cfg::DD::BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, quad = lane >> 4;
   float* zv = reinterpret_cast<float*>(smem + SM::ZVEC) + wave * 2 * H * D;
   float* xch = reinterpret_cast<float*>(smem + SM::XCH);
-  const int QG = A.qg, ZS = NWAVES / QG;
+  const int QG = A.qg, ZS = NW / QG;
   const int qgi = wave % QG, zs = wave / QG;
   const int b = blockIdx.y, n0 = (blockIdx.x * QG + qgi) * 16;
   const int n = min(n0 + col, A.N - 1);
@@ -89,9 +98,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
 
   // ---- constants -> LDS
-  for (int i = tid; i < D; i += NTHREADS) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
-  for (int i = tid; i < 2 * H * D; i += NTHREADS) c_bgb[i] = G(A.L.bgb)[i];
-  for (int i = tid; i < 2 * D; i += NTHREADS) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
+  for (int i = tid; i < D; i += NTH) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
+  for (int i = tid; i < 2 * H * D; i += NTH) c_bgb[i] = G(A.L.bgb)[i];
+  for (int i = tid; i < 2 * D; i += NTH) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
 
   const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
   const unsigned pQ1 = (unsigned)A.L.aq1, pV1 = (unsigned)A.L.av1, pF = (unsigned)A.L.af, pGB = (unsigned)A.L.agb, pM = (unsigned)A.L.am;
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
   if constexpr (ZFOLD) P.rs2 = make_blob_rsrc(A.wz + (size_t)b * A.Z * H * PANEL_DD, (unsigned)(A.Z * H * PANEL_DD));
   else P.rs2 = P.rs;
-  first_stage<ST_DD, NWAVES, ENF_ANTIPHASE>(P, ring, pQ1, wave, lane);
+  first_stage<ST_DD, NW, ENF_ANTIPHASE>(P, ring, pQ1, wave, lane);
 
   // softmax state against a per-column reference logit (the first one seen); fp32 accumulators
   float sm_m[H], sm_l[H], sm_c[H];
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
       STAMP(1);
-      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pQ1, pV1, active, lane);
+      panel_gemm<KB, NT, BF16, ST_DD, NW>(acc, F, P, ring, pQ1, pV1, active, lane);
       STAMP(2);
       if constexpr (ZFOLD && BF16) {
         // logits on the matrix pipe: rows 0..H-1 of the A operand are u_zh (bf16, packed by enf_wz_kernel),
@@ -192,17 +201,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bv1, t, quad);
       STAMP(4);
-      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pV1, pF, active, lane);
+      panel_gemm<KB, NT, BF16, ST_DD, NW>(acc, F, P, ring, pV1, pF, active, lane);
       STAMP(5);
       make_frags<BF16, KB>(F, acc);
       relu_frags<BF16, KB>(F);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bf, t, quad);
       STAMP(6);
-      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(ENF_ABL_SAMEPANEL ? 0 : z * H * PANEL_DD), active, lane);
-      else panel_gemm<KB, NT, BF16, ST_GB>(acc, F, P, ring, pF, pGB, active, lane);
+      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(ENF_ABL_SAMEPANEL ? 0 : z * H * PANEL_DD), active, lane);
+      else panel_gemm<KB, NT, BF16, ST_GB, NW>(acc, F, P, ring, pF, pGB, active, lane);
       STAMP(7);
-      gelu_tiles<NT>(acc);
+      gelu_tiles<NT, BF16>(acc);
       float mu, rstd;
       ln_stats<NT>(acc, mu, rstd);
       const float nmr = -mu * rstd;
@@ -221,11 +230,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = rowvec(zv + H * D + h * D, t, quad);
         STAMP(10 + 4 * h);
-        panel_gemm<KB, NT, BF16, ST_DD>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
+        panel_gemm<KB, NT, BF16, ST_DD, NW>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
                                         active, lane);
       } else {
         f32x4 dummy[1];
-        gb_panel<D, BF16, ST_DD, false>(v, dummy, F, P, ring, pGB + h * PANEL_GB, pM, active, c_bgb + 2 * h * D,
+        gb_panel<D, BF16, ST_DD, false, NW>(v, dummy, F, P, ring, pGB + h * PANEL_GB, pM, active, c_bgb + 2 * h * D,
                                         zv + H * D + h * D, lane, quad);
         STAMP(9 + 4 * h);
         Frags<BF16, KB> FV;
@@ -233,11 +242,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = rowvec(c_bm, t, quad);
         STAMP(10 + 4 * h);
-        if (h + 1 < H) panel_gemm<KB, NT, BF16, ST_GB>(v, FV, P, ring, pM, pGB + (h + 1) * PANEL_GB, active, lane);
-        else panel_gemm<KB, NT, BF16, ST_DD>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane);
+        if (h + 1 < H) panel_gemm<KB, NT, BF16, ST_GB, NW>(v, FV, P, ring, pM, pGB + (h + 1) * PANEL_GB, active, lane);
+        else panel_gemm<KB, NT, BF16, ST_DD, NW>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane);
       }
       STAMP(11 + 4 * h);
-      gelu_tiles<NT>(v);
+      gelu_tiles<NT, BF16>(v);
       float mu, rstd;
       ln_stats<NT>(v, mu, rstd);
       if (active) {
@@ -339,7 +348,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_fwd_kernel(PairFwdArgs A
 
 template <int D, int H, bool BF16, bool ZFOLD>
 static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
-  using SM = PairSmem<D, H, BF16>;
+  constexpr int NW = PairWaves<ZFOLD>::NW;
+  using SM = PairSmem<D, H, BF16, NW>;
   auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -348,7 +358,7 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid((A.N + 16 * A.qg - 1) / (16 * A.qg), A.B);
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SM::TOTAL, st, A);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), SM::TOTAL, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
@@ -357,7 +367,7 @@ extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, cons
 // wz / wzb: scratch for the z-fold variant (enf_workspace: W.wz, W.wzb), or NULL for the latent-split variant
 extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, float* ybar, float* lse, char* wz, float* wzb, char* wzu,
-                                   hipStream_t st) {
+                                   int run_fold, int run_pair, hipStream_t st) {
   PairFwdArgs A;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu;
   A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
@@ -367,10 +377,13 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   A.qg = NWAVES / zs;
   const bool zfold = wz && wzb && wzu && (size_t)m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
   if (zfold) {
-    A.qg = NWAVES;
-    int rc = enf_launch_wz(m, L, blob, lt, wz, wzb, wzu, st);
-    if (rc) return rc;
+    A.qg = PairWaves<true>::NW;
+    if (run_fold) {
+      int rc = enf_launch_wz(m, L, blob, lt, wz, wzb, wzu, st);
+      if (rc) return rc;
+    }
   }
+  if (!run_pair) return 0;
 #define ENF_CASE(DD, HH)                                                                                      \
   if (m.D == DD && m.H == HH) {                                                                               \
     if (zfold) return m.bf16 ? launch_pair_fwd<DD, HH, true, true>(A, st) : launch_pair_fwd<DD, HH, false, true>(A, st); \

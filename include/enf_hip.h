@@ -119,6 +119,8 @@ int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float
 #define ENF_STAGE_PROLOGUE 1u
 #define ENF_STAGE_PAIR 2u
 #define ENF_STAGE_TAIL 4u
+#define ENF_STAGE_FOLD 8u      /* enf_wz_kernel: per-latent folded matrices of the z-fold pair variant (no-op otherwise);
+                                  runs between PROLOGUE and PAIR, PAIR alone reuses what the workspace holds */
 int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
                        const float* sigma, const void* packed, float* out, float* ybar, float* lse,
                        void* workspace, size_t workspace_bytes, unsigned stages, void* stream);
