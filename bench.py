@@ -113,6 +113,7 @@ def roofline_leg(nef, params, coords, device, iters=20):
     e1.record()
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / iters
+    nef._ws_touch(ws)           # the workspace no longer holds any autograd graph's latent table
     flops = b * N * pair_flops_per_query()
     bf16 = nef.precision == "bf16"
     peak = PEAK_BF16 if bf16 else PEAK_F32

@@ -103,6 +103,14 @@ extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_
                                     const float* sigma, const void* packed, const float* ybar, const float* lse,
                                     const float* dout, float* dp, float* da, float* dsigma, void* workspace,
                                     size_t workspace_bytes, void* stream) {
+  return enf_backward_latents_ex(d, x, x_bstride, p, a, sigma, packed, ybar, lse, dout, dp, da, dsigma, workspace,
+                                 workspace_bytes, 0u, stream);
+}
+
+extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
+                                       const float* sigma, const void* packed, const float* ybar, const float* lse,
+                                       const float* dout, float* dp, float* da, float* dsigma, void* workspace,
+                                       size_t workspace_bytes, unsigned flags, void* stream) {
   int rc = enf_check_desc(d);
   if (rc) return rc;
   if (!x || !p || !a || !packed || !ybar || !lse || !dout || !dp || !da || !dsigma || !workspace) return ENF_EINVAL;
@@ -115,8 +123,10 @@ extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_
   char* ws = (char*)workspace;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
   const char* blob = (const char*)packed;
-  // the latent table is recomputed (cheap) so the call does not depend on workspace contents
-  if ((rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
+  // the latent table is recomputed (cheap) so the call does not depend on workspace contents, unless the
+  // caller vouches that nothing has touched the workspace since the matching enf_forward
+  if (!(flags & ENF_BWD_REUSE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st)))
+    return rc;
   if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, st))) return rc;
   if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
   if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr, st))) return rc;

@@ -76,6 +76,8 @@ struct EnfLayout {
   size_t stem_w, stem_b, lna_g, lna_b, wk, bk, wv, bv;
   size_t mu;     // H x (D x D): u_h[i] = sum_d mu[h][i][d] * k_h[d]
   size_t cvec;   // H x D:       c_h    = sum_d cvec[h][d] * k_h[d]
+  size_t mut;    // H x (D x D): mu transposed per head ([h][d][i]) for the forward prologue's coalesced reads
+  size_t wkt, wvt;   // HD x D: a_to_k / a_to_v kernels transposed, for the prologue backward
   // ---- coefficient A-operands of t = coeff^T inv (fp32 16x16x4 MFMA), [D/32 t-tiles][64 lanes]
   size_t acq, acv;
   // ---- accumulator-init vectors, fp32
@@ -110,6 +112,7 @@ inline EnfLayout enf_layout(const EnfDims& m) {
   L.stem_w = take(f * C * D); L.stem_b = take(f * D); L.lna_g = take(f * D); L.lna_b = take(f * D);
   L.wk = take(f * D * HD); L.bk = take(f * HD); L.wv = take(f * D * HD); L.bv = take(f * HD);
   L.mu = take(f * H * D * D); L.cvec = take(f * H * D);
+  L.mut = take(f * H * D * D); L.wkt = take(f * HD * D); L.wvt = take(f * HD * D);
   L.acq = take(f * (D / 32) * 64); L.acv = take(f * (D / 32) * 64);   // D/32 t-tiles x 64 lanes
   L.bq1 = take(f * D); L.bv1 = take(f * D); L.bf = take(f * D); L.bgb = take(f * 2 * HD); L.bm = take(f * D);
   L.bB = take(f * HD); L.bF1 = take(f * HD); L.bO0 = take(f * D); L.bO2 = take(f * D); L.bO4 = take(f * 32 * m.OB);

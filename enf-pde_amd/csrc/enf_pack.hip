@@ -41,6 +41,11 @@ __global__ void reorder_gb_kernel(float* dst, const float* src, const float* g, 
   const int h = jj / (2 * D), w = jj % (2 * D), blk = w / 32, ii = w % 32, m = blk >> 1, t = blk & 1;
   dst[(size_t)i * 2 * HD + jj] = (g ? g[i] : 1.f) * src[(size_t)i * 2 * HD + t * HD + h * D + 32 * m + ii];
 }
+// dst (cols x rows) = src (rows x cols)^T
+__global__ void transpose_kernel(float* dst, const float* src, int rows, int cols) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j < cols && i < rows) dst[(size_t)j * rows + i] = src[(size_t)i * cols + j];
+}
 // zero-padded copy of a (rows x cols) matrix into (rows x cols_pad)
 __global__ void padcopy_kernel(float* dst, const float* src, int rows, int cols, int cols_pad) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
@@ -219,6 +224,12 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
     if ((rc = mm(st, F(L.mu) + (size_t)h * D * D, D, T[ENF_W_RQ_W2], D, T[ENF_W_Q_W] + h * D, HD, D, D, D, scale, nullptr, 0))) return rc;
     if ((rc = mm(st, F(L.cvec) + (size_t)h * D, D, T[ENF_W_RQ_B2], D, T[ENF_W_Q_W] + h * D, HD, 1, D, D, scale, T[ENF_W_Q_B] + h * D, 0))) return rc;
   }
+  for (int h = 0; h < H; ++h)
+    hipLaunchKernelGGL(transpose_kernel, dim3((D + 127) / 128, D), dim3(128), 0, st, F(L.mut) + (size_t)h * D * D,
+                       F(L.mu) + (size_t)h * D * D, D, D);
+  hipLaunchKernelGGL(transpose_kernel, dim3((HD + 127) / 128, D), dim3(128), 0, st, F(L.wkt), T[ENF_W_K_W], D, HD);
+  hipLaunchKernelGGL(transpose_kernel, dim3((HD + 127) / 128, D), dim3(128), 0, st, F(L.wvt), T[ENF_W_V_W], D, HD);
+  if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
   // ---- per-pair biases
   CK(cp(L.bq1, T[ENF_W_RQ_B1], D)); CK(cp(L.bv1, T[ENF_W_RV_B1], D)); CK(cp(L.bm, T[ENF_W_MX_B0], D));
   if ((rc = mm(st, F(L.bf), D, T[ENF_W_RV_B2], D, T[ENF_W_F1_W0], D, 1, D, D, 1.f, T[ENF_W_F1_B0], 0))) return rc;
@@ -261,17 +272,19 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
 }
 
 // ---------------------------------------------------------------- K1 latent prologue
-constexpr int ZT = 8;  // latents per block: every weight element is read once per 8 latents
+// One block = ZT consecutive (b,z) rows, 256 threads.  Every weight matrix is read with the OUTPUT index on the
+// lanes (coalesced: stem_w, wk, wv are (in,out) row-major; the logit fold uses the transposed copy muT) and every
+// weight element is read once per ZT latents.  Activations sit in LDS as [feature][latent] so that one
+// ds_read_b128 pair broadcasts the ZT values a weight element multiplies.  LayerNorm: one wave per row.
+#ifndef ENF_PROLOGUE_ZT
+#define ENF_PROLOGUE_ZT 4
+#endif
+constexpr int ZT = ENF_PROLOGUE_ZT;   // latents per block (multiple of 4)
+typedef float pf4 __attribute__((ext_vector_type(4)));
 
-static __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nthreads) {
-  // sum over the block (nthreads multiple of 64, <= 256); red: 8 floats of LDS
+static __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-  for (int w = 0; w < nthreads / 64; ++w) s += red[w];
-  return s;
+  return v;
 }
 
 struct PrologueArgs {
@@ -281,21 +294,19 @@ struct PrologueArgs {
   int BZ, H, D, C, dp, inv;
 };
 
-// one block = ZT consecutive (b,z) rows; 256 threads
 __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int D = A.D, H = A.H, HD = H * D, C = A.C;
-  float* s_a = sm;                 // ZT x C
-  float* s_an = s_a + ZT * C;      // ZT x D
-  float* s_k = s_an + ZT * D;      // ZT x HD
-  float* s_red = s_k + ZT * HD;    // 8
-  const int tid = threadIdx.x;
+  float* s_a = sm;                 // [C][ZT]
+  float* s_an = s_a + ZT * C;      // [D][ZT]   stem output, then the normalised + affine row
+  float* s_k = s_an + ZT * D;      // [HD][ZT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * ZT;
   auto W = [&](size_t off) { return reinterpret_cast<const float*>(A.blob + off); };
   const int stride = enf_lt_stride(H, D);
   for (int i = tid; i < ZT * C; i += 256) {
-    const int r = row0 + i / C;
-    s_a[i] = r < A.BZ ? A.a[(size_t)r * C + i % C] : 0.f;
+    const int zz = i / C, c = i % C, r = row0 + zz;
+    s_a[c * ZT + zz] = r < A.BZ ? A.a[(size_t)r * C + c] : 0.f;
   }
   __syncthreads();
   // stem: s = a @ Ws + bs  (NEF:220)
@@ -304,36 +315,39 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
     const float bs = W(A.L.stem_b)[d];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = bs;
+#pragma unroll 4
     for (int c = 0; c < C; ++c) {
       const float w = W(A.L.stem_w)[(size_t)c * D + d];
 #pragma unroll
-      for (int zz = 0; zz < ZT; ++zz) acc[zz] = fmaf(s_a[zz * C + c], w, acc[zz]);
+      for (int q = 0; q < ZT / 4; ++q) {
+        const pf4 x = *reinterpret_cast<const pf4*>(s_a + c * ZT + 4 * q);
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) acc[4 * q + zz] = fmaf(x[zz], w, acc[4 * q + zz]);
+      }
     }
 #pragma unroll
-    for (int zz = 0; zz < ZT; ++zz) s_an[zz * D + d] = acc[zz];
+    for (int zz = 0; zz < ZT; ++zz) s_an[d * ZT + zz] = acc[zz];
   }
   __syncthreads();
-  // LayerNorm (NEF:56): biased variance, eps 1e-6
-  for (int zz = 0; zz < ZT; ++zz) {
+  // LayerNorm (NEF:56): biased variance, eps 1e-6; one wave per row
+  for (int zz = wave; zz < ZT; zz += 4) {
     const int r = row0 + zz;
     float v = 0.f;
-    for (int d = tid; d < D; d += 256) v += s_an[zz * D + d];
-    const float mu = block_sum(v, s_red, tid, 256) / D;
+    for (int d = lane; d < D; d += 64) v += s_an[d * ZT + zz];
+    const float mu = wave_sum(v) / D;
     float q = 0.f;
-    for (int d = tid; d < D; d += 256) { const float t = s_an[zz * D + d] - mu; q += t * t; }
-    const float var = block_sum(q, s_red, tid, 256) / D;
-    const float rstd = rsqrtf(var + 1e-6f);
-    __syncthreads();
-    for (int d = tid; d < D; d += 256) {
-      const float s = s_an[zz * D + d];
-      const float xn = (s - mu) * rstd;
+    for (int d = lane; d < D; d += 64) { const float t = s_an[d * ZT + zz] - mu; q += t * t; }
+    const float rstd = rsqrtf(wave_sum(q) / D + 1e-6f);
+    for (int d = lane; d < D; d += 64) {
+      const float sv = s_an[d * ZT + zz];
+      const float xn = (sv - mu) * rstd;
       if (r < A.BZ) {
-        A.an[(size_t)r * (2 * D + 2) + d] = s;           // stem output (pre-LN)
+        A.an[(size_t)r * (2 * D + 2) + d] = sv;          // stem output (pre-LN)
         A.an[(size_t)r * (2 * D + 2) + D + d] = xn;      // normalised, before scale/bias
       }
-      s_an[zz * D + d] = xn * W(A.L.lna_g)[d] + W(A.L.lna_b)[d];
+      s_an[d * ZT + zz] = xn * W(A.L.lna_g)[d] + W(A.L.lna_b)[d];
     }
-    if (tid == 0 && r < A.BZ) { A.an[(size_t)r * (2 * D + 2) + 2 * D] = mu; A.an[(size_t)r * (2 * D + 2) + 2 * D + 1] = rstd; }
+    if (lane == 0 && r < A.BZ) { A.an[(size_t)r * (2 * D + 2) + 2 * D] = mu; A.an[(size_t)r * (2 * D + 2) + 2 * D + 1] = rstd; }
   }
   __syncthreads();
   // k = an @ Wk + bk, v0 = an @ Wv + bv   (ECA:93-94)
@@ -345,15 +359,20 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
     const float bb = W(isv ? A.L.bv : A.L.bk)[jj];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = bb;
+#pragma unroll 8
     for (int d = 0; d < D; ++d) {
       const float w = Wm[(size_t)d * HD + jj];
 #pragma unroll
-      for (int zz = 0; zz < ZT; ++zz) acc[zz] = fmaf(s_an[zz * D + d], w, acc[zz]);
+      for (int q = 0; q < ZT / 4; ++q) {
+        const pf4 x = *reinterpret_cast<const pf4*>(s_an + d * ZT + 4 * q);
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) acc[4 * q + zz] = fmaf(x[zz], w, acc[4 * q + zz]);
+      }
     }
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) {
       const int r = row0 + zz;
-      if (!isv) s_k[zz * HD + jj] = acc[zz];
+      if (!isv) s_k[jj * ZT + zz] = acc[zz];
       if (r < A.BZ) {
         A.kv[(size_t)r * 2 * HD + j] = acc[zz];
         if (isv) A.lt[(size_t)r * stride + enf_lt_off_v0(H, D) + jj] = acc[zz];
@@ -361,17 +380,23 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
     }
   }
   __syncthreads();
-  // u_h = MU_h k_h ; c_h = cvec_h . k_h
+  // u_h = MU_h k_h  (muT[h][d][i]: the output index i on the lanes)
   for (int j = tid; j < HD; j += 256) {
     const int h = j / D, i = j % D;
-    const float* mu = W(A.L.mu) + ((size_t)h * D + i) * D;
+    const float* mut = W(A.L.mut) + (size_t)h * D * D + i;
     float acc[ZT];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = 0.f;
+#pragma unroll 8
     for (int dd = 0; dd < D; ++dd) {
-      const float w = mu[dd];
+      const float w = mut[(size_t)dd * D];
+      const float* kp = s_k + (h * D + dd) * ZT;
 #pragma unroll
-      for (int zz = 0; zz < ZT; ++zz) acc[zz] = fmaf(w, s_k[zz * HD + h * D + dd], acc[zz]);
+      for (int q = 0; q < ZT / 4; ++q) {
+        const pf4 x = *reinterpret_cast<const pf4*>(kp + 4 * q);
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) acc[4 * q + zz] = fmaf(x[zz], w, acc[4 * q + zz]);
+      }
     }
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) {
@@ -379,11 +404,13 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
       if (r < A.BZ) A.lt[(size_t)r * stride + enf_lt_off_u(H, D) + j] = acc[zz];
     }
   }
-  for (int t = tid; t < ZT * H; t += 256) {
+  // c_h = cvec_h . k_h : one wave per (row, head)
+  for (int t = wave; t < ZT * H; t += 4) {
     const int zz = t / H, h = t % H, r = row0 + zz;
-    float s = 0.f;
-    for (int dd = 0; dd < D; ++dd) s = fmaf(W(A.L.cvec)[h * D + dd], s_k[zz * HD + h * D + dd], s);
-    if (r < A.BZ) A.lt[(size_t)r * stride + enf_lt_off_c(H, D) + h] = s;
+    float sacc = 0.f;
+    for (int dd = lane; dd < D; dd += 64) sacc = fmaf(W(A.L.cvec)[h * D + dd], s_k[(h * D + dd) * ZT + zz], sacc);
+    sacc = wave_sum(sacc);
+    if (lane == 0 && r < A.BZ) A.lt[(size_t)r * stride + enf_lt_off_c(H, D) + h] = sacc;
   }
   // pose embed (NEF:214-217) + window coefficient
   if (tid < ZT) {
@@ -411,13 +438,15 @@ extern "C" int enf_launch_prologue(const EnfDims& m, const EnfLayout& L, const c
   PrologueArgs A;
   A.p = p; A.a = a; A.sigma = sigma; A.blob = blob; A.L = L; A.lt = lt; A.an = an; A.kv = kv;
   A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp = m.dp; A.inv = m.inv;
-  const size_t smem = sizeof(float) * (ZT * m.C + ZT * m.D + ZT * m.HD + 8);
+  const size_t smem = sizeof(float) * (ZT * m.C + ZT * m.D + ZT * m.HD);
   hipLaunchKernelGGL(enf_prologue_kernel, dim3((A.BZ + ZT - 1) / ZT), dim3(256), smem, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
 // ---------------------------------------------------------------- K1 backward
-// dlt (B*Z rows: du | dv0 | dc | dpose | dwcoef) -> dp, da, dsigma
+// dlt (B*Z rows: du | dv0 | dc | dpose | dwcoef) -> dp, da, dsigma.  Same scheme as the forward: gradient rows
+// staged in LDS as [feature][latent], the reduction index off the lanes (mu as stored is [h][i][d], i.e. the
+// output d of the transposed product is contiguous; a_to_k / a_to_v use their transposed copies wkT / wvT).
 struct PrologueBwdArgs {
   const float* p; const float* sigma; const char* blob; EnfLayout L;
   const float* an; const float* kv; const float* dlt;
@@ -426,77 +455,89 @@ struct PrologueBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int D = A.D, H = A.H, HD = H * D, C = A.C;
-  float* s_dk = sm;               // ZT x 2HD  (dk | dv0)
-  float* s_dan = s_dk + ZT * 2 * HD;  // ZT x D
-  float* s_red = s_dan + ZT * D;  // 8
-  const int tid = threadIdx.x, row0 = blockIdx.x * ZT;
+  float* s_du = sm;                    // [HD][ZT]  d u
+  float* s_dk = s_du + ZT * HD;        // [2HD][ZT] d k | d v0
+  float* s_dan = s_dk + ZT * 2 * HD;   // [D][ZT]
+  float* s_dc = s_dan + ZT * D;        // [H][ZT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * ZT;
   const int stride = enf_lt_stride(H, D);
   auto W = [&](size_t off) { return reinterpret_cast<const float*>(A.blob + off); };
-  // dk[h*D+d] = sum_i MU_h[i][d] du_h[i] + cvec_h[d] dc_h ; dv0 passes through
+  for (int t = tid; t < ZT * HD; t += 256) {
+    const int zz = t / HD, j = t % HD, r = row0 + zz;
+    const float* g = A.dlt + (size_t)(r < A.BZ ? r : 0) * stride;
+    s_du[j * ZT + zz] = r < A.BZ ? g[enf_lt_off_u(H, D) + j] : 0.f;
+    s_dk[(HD + j) * ZT + zz] = r < A.BZ ? g[enf_lt_off_v0(H, D) + j] : 0.f;
+  }
+  if (tid < ZT * H) {
+    const int zz = tid / H, h = tid % H, r = row0 + zz;
+    s_dc[h * ZT + zz] = r < A.BZ ? A.dlt[(size_t)r * stride + enf_lt_off_c(H, D) + h] : 0.f;
+  }
+  __syncthreads();
+  // dk[h*D+d] = sum_i MU_h[i][d] du_h[i] + cvec_h[d] dc_h
   for (int j = tid; j < HD; j += 256) {
     const int h = j / D, dd = j % D;
-    float acc[ZT];
     const float cv = W(A.L.cvec)[h * D + dd];
+    const float* mu = W(A.L.mu) + (size_t)h * D * D + dd;
+    float acc[ZT];
 #pragma unroll
-    for (int zz = 0; zz < ZT; ++zz) {
-      const int r = row0 + zz;
-      acc[zz] = r < A.BZ ? cv * A.dlt[(size_t)r * stride + enf_lt_off_c(H, D) + h] : 0.f;
-    }
+    for (int zz = 0; zz < ZT; ++zz) acc[zz] = cv * s_dc[h * ZT + zz];
+#pragma unroll 8
     for (int i = 0; i < D; ++i) {
-      const float w = W(A.L.mu)[((size_t)h * D + i) * D + dd];
+      const float w = mu[(size_t)i * D];
+      const float* gp = s_du + (h * D + i) * ZT;
 #pragma unroll
-      for (int zz = 0; zz < ZT; ++zz) {
-        const int r = row0 + zz;
-        const float du = r < A.BZ ? A.dlt[(size_t)r * stride + enf_lt_off_u(H, D) + h * D + i] : 0.f;
-        acc[zz] = fmaf(w, du, acc[zz]);
+      for (int q = 0; q < ZT / 4; ++q) {
+        const pf4 x = *reinterpret_cast<const pf4*>(gp + 4 * q);
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) acc[4 * q + zz] = fmaf(x[zz], w, acc[4 * q + zz]);
       }
     }
 #pragma unroll
-    for (int zz = 0; zz < ZT; ++zz) {
-      const int r = row0 + zz;
-      s_dk[zz * 2 * HD + j] = acc[zz];
-      s_dk[zz * 2 * HD + HD + j] = r < A.BZ ? A.dlt[(size_t)r * stride + enf_lt_off_v0(H, D) + j] : 0.f;
-    }
+    for (int zz = 0; zz < ZT; ++zz) s_dk[j * ZT + zz] = acc[zz];
   }
   __syncthreads();
-  // d(an_affine)[d] = sum_j Wk[d][j] dk[j] + Wv[d][j] dv0[j]; then through scale: dxn = dy * g
+  // d(an_affine)[d] = sum_j Wk[d][j] dk[j] + Wv[d][j] dv0[j]  (wkT/wvT: [j][d]); then through scale: dxn = dy * g
   for (int d = tid; d < D; d += 256) {
     float acc[ZT];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = 0.f;
+    const float* wkt = W(A.L.wkt) + d;
+    const float* wvt = W(A.L.wvt) + d;
+#pragma unroll 4
     for (int j = 0; j < HD; ++j) {
-      const float wk = W(A.L.wk)[(size_t)d * HD + j], wv = W(A.L.wv)[(size_t)d * HD + j];
+      const float wk = wkt[(size_t)j * D], wv = wvt[(size_t)j * D];
 #pragma unroll
-      for (int zz = 0; zz < ZT; ++zz)
-        acc[zz] = fmaf(wk, s_dk[zz * 2 * HD + j], fmaf(wv, s_dk[zz * 2 * HD + HD + j], acc[zz]));
+      for (int q = 0; q < ZT / 4; ++q) {
+        const pf4 kq = *reinterpret_cast<const pf4*>(s_dk + j * ZT + 4 * q), vq = *reinterpret_cast<const pf4*>(s_dk + (HD + j) * ZT + 4 * q);
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) acc[4 * q + zz] = fmaf(wk, kq[zz], fmaf(wv, vq[zz], acc[4 * q + zz]));
+      }
     }
     const float g = W(A.L.lna_g)[d];
 #pragma unroll
-    for (int zz = 0; zz < ZT; ++zz) s_dan[zz * D + d] = acc[zz] * g;
+    for (int zz = 0; zz < ZT; ++zz) s_dan[d * ZT + zz] = acc[zz] * g;
   }
   __syncthreads();
-  // LayerNorm backward: ds = rstd * (dxn - mean(dxn) - xn * mean(dxn * xn))
-  for (int zz = 0; zz < ZT; ++zz) {
+  // LayerNorm backward: ds = rstd * (dxn - mean(dxn) - xn * mean(dxn * xn)); one wave per row
+  for (int zz = wave; zz < ZT; zz += 4) {
     const int r = row0 + zz;
     const int rr = r < A.BZ ? r : A.BZ - 1;
     const float* anr = A.an + (size_t)rr * (2 * D + 2);
     float v1 = 0.f, v2 = 0.f;
-    for (int d = tid; d < D; d += 256) { const float g = s_dan[zz * D + d]; v1 += g; v2 += g * anr[D + d]; }
-    const float m1 = block_sum(v1, s_red, tid, 256) / D;
-    const float m2 = block_sum(v2, s_red, tid, 256) / D;
+    for (int d = lane; d < D; d += 64) { const float g = s_dan[d * ZT + zz]; v1 += g; v2 += g * anr[D + d]; }
+    const float m1 = wave_sum(v1) / D, m2 = wave_sum(v2) / D;
     const float rstd = anr[2 * D + 1];
-    __syncthreads();
-    for (int d = tid; d < D; d += 256) s_dan[zz * D + d] = rstd * (s_dan[zz * D + d] - m1 - anr[D + d] * m2);
+    for (int d = lane; d < D; d += 64) s_dan[d * ZT + zz] = rstd * (s_dan[d * ZT + zz] - m1 - anr[D + d] * m2);
   }
   __syncthreads();
   // da[c] = sum_d Ws[c][d] ds[d]
   for (int t = tid; t < ZT * C; t += 256) {
     const int zz = t / C, c = t % C, r = row0 + zz;
-    float s = 0.f;
-    for (int d = 0; d < D; ++d) s = fmaf(W(A.L.stem_w)[(size_t)c * D + d], s_dan[zz * D + d], s);
-    if (r < A.BZ) A.da[(size_t)r * C + c] = s;
+    float sacc = 0.f;
+    for (int d = 0; d < D; ++d) sacc = fmaf(W(A.L.stem_w)[(size_t)c * D + d], s_dan[d * ZT + zz], sacc);
+    if (r < A.BZ) A.da[(size_t)r * C + c] = sacc;
   }
   if (tid < ZT) {
     const int r = row0 + tid;
@@ -523,7 +564,7 @@ extern "C" int enf_launch_prologue_bwd(const EnfDims& m, const EnfLayout& L, con
   A.p = p; A.sigma = sigma; A.blob = blob; A.L = L; A.an = an; A.kv = kv; A.dlt = dlt;
   A.dp = dp; A.da = da; A.dsigma = dsigma;
   A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp_dim = m.dp; A.inv = m.inv;
-  const size_t smem = sizeof(float) * (ZT * 2 * m.HD + ZT * m.D + 8);
+  const size_t smem = sizeof(float) * (ZT * 3 * m.HD + ZT * m.D + ZT * m.H);
   hipLaunchKernelGGL(enf_prologue_bwd_kernel, dim3((A.BZ + ZT - 1) / ZT), dim3(256), smem, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }

@@ -90,6 +90,7 @@ class _EnfFunction(torch.autograd.Function):
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.enf_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
                                    _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), st))
+        ctx.ws_tag = model._ws_touch(ws)      # backward may reuse the latent table if nothing else used the workspace
         ctx.model = model
         ctx.has_sigma = sigma is not None
         ctx.xstride = xstride
@@ -113,9 +114,11 @@ class _EnfFunction(torch.autograd.Function):
         dsig = torch.empty((B, Z, 1), device=dev, dtype=torch.float32)
         ws = model._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.enf_backward_latents(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(p_), _ptr(a_), _ptr(sigma),
-                                            _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
-                                            _ptr(dsig), _ptr(ws), ws.numel(), st))
+        reuse = 1 if model._ws_tag(ws) == ctx.ws_tag else 0          # ENF_BWD_REUSE_PROLOGUE
+        _lib.check(lib.enf_backward_latents_ex(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(p_), _ptr(a_), _ptr(sigma),
+                                               _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
+                                               _ptr(dsig), _ptr(ws), ws.numel(), reuse, st))
+        model._ws_touch(ws)
         return None, dp, da, (dsig if ctx.has_sigma else None), None, None
 
 
@@ -155,6 +158,8 @@ class EquivariantCrossAttentionNeF:
         self.precision = precision
         self._pack_cache = {}
         self._ws_cache = {}
+        self._ws_gen = 0
+        self._ws_tags = {}
 
     # ------------------------------------------------------------------ descriptors / buffers
     def _desc(self, B, N, Z):
@@ -174,6 +179,15 @@ class EquivariantCrossAttentionNeF:
             ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
             self._ws_cache[key] = ws
         return ws
+
+    def _ws_touch(self, ws):
+        """Mark a use of workspace `ws`; returns the tag identifying this use."""
+        self._ws_gen += 1
+        self._ws_tags[ws.data_ptr()] = self._ws_gen
+        return (ws.data_ptr(), self._ws_gen)
+
+    def _ws_tag(self, ws):
+        return (ws.data_ptr(), self._ws_tags.get(ws.data_ptr()))
 
     @staticmethod
     def _x_arg(x):

@@ -132,6 +132,13 @@ int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, co
                          const float* a, const float* sigma, const void* packed, const float* ybar,
                          const float* lse, const float* dout, float* dp, float* da, float* dsigma,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* flags: ENF_BWD_REUSE_PROLOGUE = the workspace still holds the latent table of the enf_forward call with the same
+ * (p, a, sigma, weights) -- nothing else has used it since -- so the prologue is not recomputed. */
+#define ENF_BWD_REUSE_PROLOGUE 1u
+int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p,
+                         const float* a, const float* sigma, const void* packed, const float* ybar,
+                         const float* lse, const float* dout, float* dp, float* da, float* dsigma,
+                         void* workspace, size_t workspace_bytes, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training path: gradients w.r.t. the network weights (value_and_grad over params['nef'],
