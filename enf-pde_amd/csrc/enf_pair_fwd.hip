@@ -27,6 +27,7 @@ struct PairFwdArgs {
   const float* lt; const char* blob; EnfLayout L;
   float* ybar; float* lse;
   const char* wz; const float* wzb; const char* wzu;   // z-fold only: per-latent mixer-input panels / biases (enf_wz.hip)
+  int xcd_remap;                          // z-fold: 1 when B % 8 == 0 (see the kernel)
   int B, N, Z, dx, inv, use_window, qg;   // qg: query groups per workgroup (1,2,4,8); ZS = 8/qg
 };
 
@@ -92,7 +93,16 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   float* xch = reinterpret_cast<float*>(smem + SM::XCH);
   const int QG = A.qg, ZS = NW / QG;
   const int qgi = wave % QG, zs = wave / QG;
-  const int b = blockIdx.y, n0 = (blockIdx.x * QG + qgi) * 16;
+  // XCD-aware placement (z-fold, B % 8 == 0): workgroup ids go round-robin over the 8 XCDs, and every workgroup of
+  // a signal streams that signal's per-latent panels, so all of a signal's workgroups are given ids of ONE residue
+  // mod 8: its 64 KB x Z of panels then enter one XCD's L2 instead of eight (HBM/fabric fetches 540 -> ~70 MB).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (ZFOLD && A.xcd_remap) {
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, slot = id >> 3;
+    by = xcd + 8 * (slot / (int)gridDim.x);
+    bx = slot % (int)gridDim.x;
+  }
+  const int b = by, n0 = (bx * QG + qgi) * 16;
   const int n = min(n0 + col, A.N - 1);
   const char* blob = A.blob;
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
@@ -376,6 +386,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;
   A.qg = NWAVES / zs;
   const bool zfold = wz && wzb && wzu && (size_t)m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
+  A.xcd_remap = zfold && m.B % 8 == 0;
   if (zfold) {
     A.qg = PairWaves<true>::NW;
     if (run_fold) {
