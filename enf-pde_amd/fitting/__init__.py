@@ -4,10 +4,12 @@
   inner_loop(...)      trainers/pde_trainer.py:122-235         MAML inner loop: per-signal latent SGD
   decode(...)          trainers/pde_trainer.py:389-405         full-grid decode (chunking optional)
   shard_signals / allreduce_mean_   SURVEY.md 8e               meta-batch data parallelism over RCCL
+  MetaSGDPDETrainer    trainers/pde_trainer.py:60-67,237-288   outer (meta) step: meta-gradient + optax-rule optimisers
 """
 from .model import get_model_pde
 from .inner_loop import inner_loop, decode, make_masks, default_meta_sgd_lrs
 from .parallel import shard_range, allreduce_mean_, init_distributed
+from .trainers import MetaSGDPDETrainer, TrainState, meta_gradients
 
 __all__ = ["get_model_pde", "inner_loop", "decode", "make_masks", "default_meta_sgd_lrs", "shard_range",
-           "allreduce_mean_", "init_distributed"]
+           "allreduce_mean_", "init_distributed", "MetaSGDPDETrainer", "TrainState", "meta_gradients"]

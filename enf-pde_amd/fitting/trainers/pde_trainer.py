@@ -1,0 +1,224 @@
+"""Outer (meta) step of the ENF trainer -- the nef phase of experiments/fitting/trainers/pde_trainer.py.
+
+Reference:  recon_loss, grads = jax.value_and_grad(self.enf_loss)(params, state, trajectory)   (pde_trainer.py:255)
+where enf_loss = the loss of the LAST inner step after S meta-SGD steps from the shared latent initialisation
+(pde_trainer.py:122-235, 483-531), differentiated w.r.t. params = {nef, autodecoder, meta_sgd_lrs} THROUGH the
+inner steps, followed by clip_by_global_norm(1) + AdamW on nef, Adam on the latent initialisation when
+learning_rate_codes != 0, Adam on the inner learning rates and clip(lrs, 1e-6, 10)   (pde_trainer.py:258-273).
+
+Here the decoder is once-differentiable (hand-written HIP backward), so the meta-gradient is assembled by the
+adjoint recursion over the inner steps
+
+    phi_{s+1} = phi_s - alpha * g_s(phi_s, theta),          g_s = B grad_phi L_s  (sigma masked)
+    lambda_S  = grad_phi L_S(phi_S),   g_theta = grad_theta L_S(phi_S)
+    lambda_s  = lambda_{s+1} - B H_s w,      g_theta -= B d/dtheta[grad_phi L_s . w],      w = alpha * lambda_{s+1}
+    g_alpha  -= sum lambda_{s+1} * g_s
+
+whose only second-order objects are Hessian(-mixed)-vector products along ONE direction w per step.
+``second_order="fd"`` evaluates them by central differences of first-order gradients at phi_s +- eps w (two
+extra forward+backward passes with weight gradients per inner step; ``fd_step`` = the largest component of the
+perturbation); ``second_order="none"`` drops them (first-order MAML).
+
+Accuracy against exact double-backward of the oracle (scripts/meta_grad_err.py, tests/test_gpu_trainer.py; f32
+mode): first-order MAML is off by 7-50 % per tensor on the test problems -- the second-order terms matter; the
+finite-difference form brings 42 of the 46 weight tensors, the latent features and the inner learning rates to
+~1e-3..1e-2.  The four tensors feeding a relu (layers_0 kernel/bias of the two RFFNets) and the position
+initialisation stay at 2-20 %: a finite perturbation flips relu masks, which automatic differentiation (the
+reference's jax.grad, and the oracle) never sees; the flips act as noise that shrinks with more pairs and a larger
+step.  An exact a.e. second-order term needs tangent-mode (JVP) pair kernels -- not built.
+"""
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+
+import torch
+
+from ..inner_loop import _pose, make_masks
+from ..optim import Adam, AdamW, clip_by_global_norm
+from ..parallel import allreduce_mean_
+from ...enf.models import TENSOR_PATHS, _get, _set
+
+LATENT_KEYS = ("p_pos", "p_ori", "a", "gaussian_window")
+
+
+def _tree_from_tensors(tensors):
+    out = {}
+    for path, t in zip(TENSOR_PATHS, tensors):
+        _set(out, path, t)
+    return {"params": out}
+
+
+def _loss(nef, params, coords, img, masks, s, lat):
+    B = img.shape[0]
+    n_ori = nef.cross_attn_invariant.num_z_ori_dims
+    xs = coords[masks[:, s]][None].expand(B, -1, -1)                    # pde_trainer.py:193-197
+    ys = img[:, masks[:, s]]
+    out = nef.apply(params, xs, _pose(lat, n_ori), lat["a"], lat.get("gaussian_window"))
+    return ((out - ys) ** 2).mean()                                     # pde_trainer.py:185
+
+
+def _latent_grads(nef, params, coords, img, masks, s, lat, keys):
+    leaves = {k: lat[k].detach().requires_grad_(True) for k in lat}
+    g = torch.autograd.grad(_loss(nef, params, coords, img, masks, s, leaves), [leaves[k] for k in keys], allow_unused=True)
+    return {k: (torch.zeros_like(lat[k]) if gk is None else gk) for k, gk in zip(keys, g)}
+
+
+def _full_grads(nef, weights, coords, img, masks, s, lat, keys):
+    """(loss, grads w.r.t. the 46 weight tensors, grads w.r.t. the latents) on the training path."""
+    w = [t.detach().requires_grad_(True) for t in weights]
+    leaves = {k: lat[k].detach().requires_grad_(True) for k in lat}
+    loss = _loss(nef, _tree_from_tensors(w), coords, img, masks, s, leaves)
+    g = torch.autograd.grad(loss, w + [leaves[k] for k in keys], allow_unused=True)
+    gw = [torch.zeros_like(t) if gi is None else gi for t, gi in zip(w, g[:len(w)])]
+    gl = {k: (torch.zeros_like(lat[k]) if gi is None else gi) for k, gi in zip(keys, g[len(w):])}
+    return loss.detach(), gw, gl
+
+
+def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaussian_window=False,
+                   second_order="fd", fd_step=2e-2, noise_pos=0.0, generator=None):
+    """Value and gradient of the last-inner-step loss w.r.t. (nef weights, meta-init latents, inner lrs).
+
+    Returns (loss, grads) with grads = {'nef': [46 tensors in ENF_W_* order], 'autodecoder': {key: (1,Z,.)},
+    'meta_sgd_lrs': {key: like lrs[key]}}.
+    """
+    if second_order not in ("fd", "none"):
+        raise ValueError("second_order must be 'fd' or 'none'")
+    B = img.shape[0]
+    S = masks.shape[1] - 1
+    weights = nef.param_tensors(nef_params)
+    frozen = _tree_from_tensors([t.detach() for t in weights])           # inference path for the inner steps
+    lat = {k: v.detach().repeat_interleave(B, dim=0).clone() for k, v in latents0.items()}
+    if noise_pos:
+        lat["p_pos"] = lat["p_pos"] + torch.randn(lat["p_pos"].shape, generator=generator, device="cpu").to(lat["p_pos"].device) * noise_pos
+    keys = [k for k in lat if not (k == "gaussian_window" and not nef.use_gaussian_window)]
+
+    def masked(k):          # sigma takes part in the inner update only when asked to (pde_trainer.py:210-212)
+        return k == "gaussian_window" and not optimize_gaussian_window
+
+    # ---- forward sweep, keeping every phi_s and g_s
+    phis, gs = [], []
+    for s in range(S):
+        g = _latent_grads(nef, frozen, coords, img, masks, s, lat, keys)
+        g = {k: (torch.zeros_like(lat[k]) if (k not in g or masked(k)) else g[k] * B) for k in lat}    # pde_trainer.py:207
+        phis.append(lat)
+        gs.append(g)
+        lat = {k: (lat[k] - lrs[k] * g[k]).detach() for k in lat}                                       # pde_trainer.py:215-219
+    # ---- last step: value, d/d theta, lambda_S
+    loss, g_theta, lam = _full_grads(nef, weights, coords, img, masks, S, lat, keys)
+    lam = {k: lam.get(k, torch.zeros_like(lat[k])) for k in lat}
+    g_alpha = {k: torch.zeros_like(lrs[k]) for k in lrs}
+    # ---- adjoint sweep
+    for s in reversed(range(S)):
+        for k in lrs:
+            if k in lam and not masked(k):
+                prod = lam[k] * gs[s][k]
+                g_alpha[k] -= prod.sum(dim=(0, 1)) if lrs[k].numel() > 1 else prod.sum().reshape(lrs[k].shape)
+        if second_order == "none":
+            continue
+        w = {k: (torch.zeros_like(lam[k]) if masked(k) else lrs[k] * lam[k]) for k in lam}
+        wmax = max(float(v.abs().max()) for v in w.values())
+        if wmax == 0.0:
+            continue
+        eps = fd_step / wmax
+        plus = {k: phis[s][k] + eps * w[k] for k in lam}
+        minus = {k: phis[s][k] - eps * w[k] for k in lam}
+        _, gw_p, gl_p = _full_grads(nef, weights, coords, img, masks, s, plus, keys)
+        _, gw_m, gl_m = _full_grads(nef, weights, coords, img, masks, s, minus, keys)
+        c = B / (2.0 * eps)
+        g_theta = [gt - c * (a - b) for gt, a, b in zip(g_theta, gw_p, gw_m)]
+        lam = {k: lam[k] - c * (gl_p.get(k, 0) - gl_m.get(k, 0)) if k in gl_p else lam[k] for k in lam}
+    g_lat0 = {k: lam[k].sum(dim=0, keepdim=True) for k in lam}
+    return loss, {"nef": g_theta, "autodecoder": g_lat0, "meta_sgd_lrs": g_alpha}
+
+
+@dataclass
+class TrainState:
+    params: dict
+    nef_opt_state: dict
+    autodecoder_opt_state: dict
+    meta_sgd_opt_state: dict
+    step: int = 0
+    rng: torch.Generator = field(default_factory=lambda: torch.Generator().manual_seed(0))
+
+
+class MetaSGDPDETrainer:
+    """nef phase of MetaSGDPDETrainer (pde_trainer.py): init_train_state / nef_train_step.
+
+    ``config`` carries the reference's field names: optimizer.learning_rate_enf, optimizer.learning_rate_codes,
+    meta.learning_rate_meta_sgd, meta.num_inner_steps, meta.inner_learning_rate_{p,a,window},
+    meta.noise_pos_inner_loop, nef.optimize_gaussian_window, training.max_num_sampled_points.
+    The latent-ODE phase (ode_train_step, dual_train_step) is outside this build's scope.
+    """
+
+    def __init__(self, config, nef, outer_autodecoder, coords, seed=0, second_order="fd", fd_step=2e-2):
+        self.config, self.nef, self.outer_autodecoder, self.coords, self.seed = config, nef, outer_autodecoder, coords, seed
+        self.second_order, self.fd_step = second_order, fd_step
+        o, m = config.optimizer, config.meta
+        self.nef_opt = AdamW(o.learning_rate_enf)                              # after clip_by_global_norm(1.0)
+        self.autodecoder_opt = Adam(o.learning_rate_codes)
+        self.meta_sgd_opt = Adam(m.learning_rate_meta_sgd)
+
+    def init_train_state(self, nef_params=None):
+        cfg, dev = self.config, self.coords.device
+        g = torch.Generator().manual_seed(self.seed)
+        ad = self.outer_autodecoder.init(g, device=dev)                          # pde_trainer.py:79-81
+        C = ad["params"]["a"].shape[-1]
+        lrs = {"p_pos": torch.ones(1, device=dev) * cfg.meta.inner_learning_rate_p,           # pde_trainer.py:83-97
+               "a": torch.ones(C, device=dev) * cfg.meta.inner_learning_rate_a,
+               "gaussian_window": torch.ones(1, device=dev) * cfg.meta.inner_learning_rate_window}
+        if self.outer_autodecoder.num_ori_dims > 0:
+            lrs["p_ori"] = torch.ones(1, device=dev) * cfg.meta.inner_learning_rate_p
+        if nef_params is None:
+            nef_params = self.nef.init(g, device=dev)                            # pde_trainer.py:99-102
+        params = {"nef": nef_params, "autodecoder": ad, "meta_sgd_lrs": lrs}
+        return TrainState(params=params,
+                          nef_opt_state=self.nef_opt.init(self.nef.param_tensors(nef_params)),
+                          autodecoder_opt_state=self.autodecoder_opt.init(list(ad["params"].values())),
+                          meta_sgd_opt_state=self.meta_sgd_opt.init(list(lrs.values())),
+                          step=0, rng=g)
+
+    def _latents0(self, state):
+        P = state.params["autodecoder"]["params"]
+        keys = [k for k in LATENT_KEYS if k in P and not (k == "p_ori" and self.outer_autodecoder.num_ori_dims == 0)]
+        return {k: P[k] for k in keys}
+
+    def nef_train_step(self, state, batch, masks=None):
+        """One outer step on ``batch`` = (B, N, O) initial states (trajectory[:, 0], pde_trainer.py:485-487).
+        Returns (recon_loss, new_state).  In a multi-rank run every rank passes its shard of the meta-batch;
+        the outer gradients are averaged with one flat all-reduce before the (identical) optimiser updates."""
+        cfg = self.config
+        img = batch.reshape(batch.shape[0], -1, batch.shape[-1])
+        if masks is None:
+            masks = make_masks(self.coords.shape[0], cfg.training.max_num_sampled_points, cfg.meta.num_inner_steps,
+                               generator=state.rng, device=self.coords.device)
+        lat0 = self._latents0(state)
+        lrs = state.params["meta_sgd_lrs"]
+        loss, grads = meta_gradients(self.nef, state.params["nef"], lat0, lrs, self.coords, img, masks,
+                                     optimize_gaussian_window=getattr(cfg.nef, "optimize_gaussian_window", False),
+                                     second_order=self.second_order, fd_step=self.fd_step,
+                                     noise_pos=getattr(cfg.meta, "noise_pos_inner_loop", 0.0), generator=state.rng)
+        lat_keys, lr_keys = list(lat0.keys()), list(lrs.keys())
+        flat = grads["nef"] + [grads["autodecoder"][k] for k in lat_keys] + [grads["meta_sgd_lrs"][k] for k in lr_keys] + [loss.reshape(1)]
+        allreduce_mean_(flat)                                                    # one exchange per outer step
+        loss = flat[-1][0]
+        # nef: clip_by_global_norm(1.0) -> adamw                                  (pde_trainer.py:60-63,258-259)
+        weights = self.nef.param_tensors(state.params["nef"])
+        new_w, nef_opt_state = self.nef_opt.update(clip_by_global_norm(grads["nef"], 1.0), state.nef_opt_state, weights)
+        nef_params = _tree_from_tensors(new_w)
+        # latent initialisation: adam, only when learning_rate_codes != 0         (pde_trainer.py:261-268)
+        ad = state.params["autodecoder"]
+        ad_state = state.autodecoder_opt_state
+        if cfg.optimizer.learning_rate_codes != 0:
+            P = ad["params"]
+            names = list(P.keys())
+            g = [grads["autodecoder"].get(k, torch.zeros_like(P[k])) for k in names]
+            new_p, ad_state = self.autodecoder_opt.update(g, ad_state, [P[k] for k in names])
+            ad = {"params": dict(zip(names, new_p))}
+        # inner learning rates: adam, then clip to [1e-6, 10]                      (pde_trainer.py:270-273)
+        new_lrs, lr_state = self.meta_sgd_opt.update([grads["meta_sgd_lrs"][k] for k in lr_keys], state.meta_sgd_opt_state,
+                                                     [lrs[k] for k in lr_keys])
+        lrs = {k: v.clamp(1e-6, 10.0) for k, v in zip(lr_keys, new_lrs)}
+        new_state = TrainState(params={"nef": nef_params, "autodecoder": ad, "meta_sgd_lrs": lrs},
+                               nef_opt_state=nef_opt_state, autodecoder_opt_state=ad_state, meta_sgd_opt_state=lr_state,
+                               step=state.step + 1, rng=state.rng)
+        return loss, new_state
