@@ -21,6 +21,10 @@
 #include "enf_device.h"
 #include "enf_pair_common.h"
 
+#ifndef ENF_K3_LDSACC
+#define ENF_K3_LDSACC 1
+#endif
+
 struct PairBwdArgs {
   const float* x; long long x_bstride;
   const float* lt; const char* blob; EnfLayout L;
@@ -73,7 +77,8 @@ template <int D, int H, bool BF16> struct PairBwdSmem {
   static constexpr int GC = CONSTS + 4 * N_CONST;                          // gcq | gcv panels
   static constexpr int GC_BYTES = PanelCfg<D / 64, 1, BF16>::BYTES;
   static constexpr int ZVEC = GC + 2 * GC_BYTES;                           // NWAVES x 2HD floats
-  static constexpr int TOTAL = ZVEC + 4 * NWAVES * 2 * H * D;
+  static constexpr int LACC = ZVEC + 4 * NWAVES * 2 * H * D;               // NWAVES x (2 H D/16) x 64 lanes floats: dU | dV0 partial sums
+  static constexpr int TOTAL = LACC + (ENF_K3_LDSACC ? 4 * NWAVES * 2 * H * (D / 16) * 64 : 0);
 };
 
 // d t = d E_sin * E_cos - d E_cos * E_sin   (the 2 pi is folded into the gc panel)
@@ -263,12 +268,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 
   // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature
   // 16 t + col, summed over the queries n = 4 quad + i of every tile (flipped products).
-  float dU[H][NT], dV0[H][NT], dC[H], dpose[4] = {0.f, 0.f, 0.f, 0.f}, dwc = 0.f;
+  // ENF_K3_LDSACC: they live in wave-private LDS ([slot][lane], conflict-free) instead of 32 registers that are
+  // touched once per tile (and otherwise spilled to scratch for the whole sweep).
+#if ENF_K3_LDSACC
+  float* lacc = reinterpret_cast<float*>(smem + SM::LACC) + wave * (2 * H * NT * 64) + lane;
+  // every lane owns its slots: plain read-modify-write (an LDS float atomic costs ~1000 cycles here)
+  auto dU_add = [&](int h, int t, float v) { lacc[(h * NT + t) * 64] += v; };
+  auto dV0_add = [&](int h, int t, float v) { lacc[((H + h) * NT + t) * 64] += v; };
+  auto dU_get = [&](int h, int t) { return lacc[(h * NT + t) * 64]; };
+  auto dV0_get = [&](int h, int t) { return lacc[((H + h) * NT + t) * 64]; };
+#else
+  float dU[H][NT], dV0[H][NT];
+  auto dU_add = [&](int h, int t, float v) { dU[h][t] += v; };
+  auto dV0_add = [&](int h, int t, float v) { dV0[h][t] += v; };
+  auto dU_get = [&](int h, int t) { return dU[h][t]; };
+  auto dV0_get = [&](int h, int t) { return dV0[h][t]; };
+#endif
+  float dC[H], dpose[4] = {0.f, 0.f, 0.f, 0.f}, dwc = 0.f;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     dC[h] = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { dU[h][t] = 0.f; dV0[h][t] = 0.f; }
+    for (int t = 0; t < NT; ++t) {
+#if ENF_K3_LDSACC
+      lacc[(h * NT + t) * 64] = 0.f; lacc[((H + h) * NT + t) * 64] = 0.f;
+#else
+      dU[h][t] = 0.f; dV0[h][t] = 0.f;
+#endif
+    }
   }
 
   const int ntiles = (A.N + 15) / 16;
@@ -415,7 +442,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true>(
             v, FA, P, ring, gM, gGB + h * PANEL_GG, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
             [&](int mt, const f32x4& af) {
-              dV0[h][mt] += af[0] * opgf[mt][0] + af[1] * opgf[mt][1] + af[2] * opgf[mt][2] + af[3] * opgf[mt][3];
+              dV0_add(h, mt, af[0] * opgf[mt][0] + af[1] * opgf[mt][1] + af[2] * opgf[mt][2] + af[3] * opgf[mt][3]);
             });                                                                                               // v <- d v
       }
       BSTAMP(6 + 6 * h);
@@ -519,8 +546,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           [&](int mt, const f32x4& af) {
 #pragma unroll
             for (int h = 0; h < H; ++h)
-              dU[h][mt] += dl[h][0] * fmaxf(af[0], 0.f) + dl[h][1] * fmaxf(af[1], 0.f) + dl[h][2] * fmaxf(af[2], 0.f) +
-                           dl[h][3] * fmaxf(af[3], 0.f);
+              dU_add(h, mt, dl[h][0] * fmaxf(af[0], 0.f) + dl[h][1] * fmaxf(af[1], 0.f) + dl[h][2] * fmaxf(af[2], 0.f) +
+                                dl[h][3] * fmaxf(af[3], 0.f));
           });                                                                                                    // a1
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -565,7 +592,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float a = xquad_sum(dU[h][t]), c = xquad_sum(dV0[h][t]);
+      const float a = xquad_sum(dU_get(h, t)), c = xquad_sum(dV0_get(h, t));
       if (quad == 0) {
         atomicAdd(drow + enf_lt_off_u(H, D) + h * D + 16 * t + col, a);
         atomicAdd(drow + enf_lt_off_v0(H, D) + h * D + 16 * t + col, c);
