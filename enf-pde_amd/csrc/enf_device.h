@@ -50,6 +50,9 @@ DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
   }
 }
 
+#ifndef ENF_ASM_LITE
+#define ENF_ASM_LITE 0       // 1: asm GEMM stages keep 4 instead of 8 fragment reads in flight (register-starved kernels)
+#endif
 #ifndef ENF_GELU_PK
 #define ENF_GELU_PK 1
 #endif
@@ -104,9 +107,9 @@ template <bool BF16, int KB> DEV void relu_frags(Frags<BF16, KB>& F) {
 // Panel order (enf_pack.hip): bf16 [mt][blk][lane] x 16 B; fp32 [mt][in-tile][lane] x 16 B.
 template <bool BF16, int KB, int MTS>
 DEV void gemm_stage(f32x4* acc, const Frags<BF16, KB>& F, const char* lds, int lane) {
-  if constexpr (BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS>::available) {
+  if constexpr (BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::available) {
     // hand-scheduled stage: NBUF fragment reads in flight, MFMAs round-robin over the accumulators
-    GemmStageAsm<KB, MTS>::run(acc, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(lds) + (lane << 4)));
+    GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::run(acc, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(lds) + (lane << 4)));
     return;
   }
 #pragma unroll
@@ -218,6 +221,34 @@ template <int NT, bool FAST = false> DEV void gelu_tiles(f32x4 (&X)[NT]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) X[t][i] = gelu_f(X[t][i]);
 #endif
+  }
+}
+// gelu and its derivative from ONE exp + rcp (the backward kernel needs both for the same pre-activation):
+// X <- gelu(X), G <- gelu'(X), two values per instruction where the ISA has a packed form
+DEV void gelu_fg2(f32x2 x, f32x2& g, f32x2& dg) {
+  const float c = 0.7978845608028654f;
+  const float c2 = -2.0f * c * 1.4426950408889634f;
+  const f32x2 x2 = x * x;
+  const f32x2 u = x * (x2 * (c2 * 0.044715f) + c2);
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(u[0]);
+  e[1] = __builtin_amdgcn_exp2f(u[1]);
+  e = e + 1.0f;
+  f32x2 s;
+  s[0] = __builtin_amdgcn_rcpf(e[0]);
+  s[1] = __builtin_amdgcn_rcpf(e[1]);
+  g = x * s;
+  dg = g * (1.0f - s) * (x2 * (6.0f * c * 0.044715f) + 2.0f * c) + s;
+}
+// in place: X <- gelu(X), returns gelu'(X) in G
+template <int NT> DEV void gelu_fg_tiles(f32x4 (&X)[NT], f32x4 (&G)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f32x2 g0, d0, g1, d1;
+    gelu_fg2(f32x2{X[t][0], X[t][1]}, g0, d0);
+    gelu_fg2(f32x2{X[t][2], X[t][3]}, g1, d1);
+    X[t] = f32x4{g0[0], g0[1], g1[0], g1[1]};
+    G[t] = f32x4{d0[0], d0[1], d1[0], d1[1]};
   }
 }
 // relu without the canonicalising second v_max that fmaxf(x, 0) costs (MFMA results are never signalling)
@@ -337,12 +368,12 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
     if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     const char* slot = ring + P.cur * STAGE_MAX;
-    if constexpr (TRANS && BF16 && ENF_ASM_GEMM && GemmStageAsm<KBIN, C::MTS>::available) {
+    if constexpr (TRANS && BF16 && ENF_ASM_GEMM && GemmStageAsm<KBIN, C::MTS, ENF_ASM_LITE != 0>::available) {
       // one fragment read feeds both products (hand-scheduled stage, enf_gemm_asm.h)
       f32x4 af[C::MTS];
 #pragma unroll
       for (int mt = 0; mt < C::MTS; ++mt) af[mt] = flip_init(sp * C::MTS + mt);
-      GemmStageAsm<KBIN, C::MTS>::run_both(&acc[sp * C::MTS], af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
+      GemmStageAsm<KBIN, C::MTS, ENF_ASM_LITE != 0>::run_both(&acc[sp * C::MTS], af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
 #pragma unroll
       for (int mt = 0; mt < C::MTS; ++mt) flip(sp * C::MTS + mt, af[mt]);
     } else {

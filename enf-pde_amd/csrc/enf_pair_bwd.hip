@@ -17,10 +17,36 @@
 // gemm_tile_flip -- same panels, MFMA operands swapped) whose rows are the queries, so they cost 4
 // FMAs per 16x16 tile and 32 accumulator registers instead of 128; +160 MFMAs per tile.
 #include <hip/hip_runtime.h>
+#ifndef ENF_K3_LITE
+#define ENF_K3_LITE 0
+#endif
+#define ENF_ASM_LITE ENF_K3_LITE
 #include "enf_layout.h"
 #include "enf_device.h"
 #include "enf_pair_common.h"
 
+#ifndef ENF_K3_FENCE
+#define ENF_K3_FENCE 1
+#endif
+#if ENF_K3_FENCE
+#define K3_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define K3_SCHED_FENCE() do {} while (0)
+#endif
+#ifndef ENF_K3_OPAQUE
+#define ENF_K3_OPAQUE 1
+#endif
+#if ENF_K3_OPAQUE
+#define K3_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define K3_OPAQUE(x) do {} while (0)
+#endif
+#ifndef ENF_K3_PARK
+#define ENF_K3_PARK 1
+#endif
+#ifndef ENF_K3_FUSED_GELU
+#define ENF_K3_FUSED_GELU 0
+#endif
 #ifndef ENF_K3_LDSACC
 #define ENF_K3_LDSACC 1
 #endif
@@ -105,7 +131,7 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
     f32x4 t[MTS];
 #pragma unroll
     for (int j = 0; j < MTS; ++j) t[j] = rowvec(bias, sp * MTS + j, quad);
-    constexpr bool ASM = BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS>::available && MTS == 8;
+    constexpr bool ASM = BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::available && MTS == 8;
     if constexpr (ASM) {
       // transposed product of all 8 tiles + flipped product of the 4 gamma tiles {0,1,4,5} from one fragment read
       f32x4 af[4];
@@ -114,7 +140,7 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
         const float bc = 1.0f + bias[16 * (sp * MTS + 4 * (j >> 1) + (j & 1)) + col];
         af[j] = f32x4{bc, bc, bc, bc};
       }
-      GemmStageAsm<KB, MTS>::run_gb(t, af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
+      GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::run_gb(t, af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
 #pragma unroll
       for (int j = 0; j < 4; ++j) opgf[2 * (sp * (MTS / 4) + (j >> 1)) + (j & 1)] = af[j];
     } else {
@@ -227,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   float* c_bq1 = cst, *c_bv1 = cst + D, *c_bf = cst + 2 * D, *c_bm = cst + 3 * D, *c_bgb = cst + 4 * D;
   float* c_acq = c_bgb + 2 * H * D, *c_acv = c_acq + 2 * D;
   char* gcq = smem + SM::GC, *gcv = gcq + SM::GC_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, quad = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 15, quad = lane >> 4;
   float* zv = reinterpret_cast<float*>(smem + SM::ZVEC) + wave * 2 * H * D;
   const char* blob = A.blob;
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
@@ -338,9 +364,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     BSTAMP(1);
     // ---------------- v-forward to the normalised f
     unsigned relu_mask = 0u;             // bit (4t + i): a2[t][i] > 0
+#if ENF_K3_PARK
+    Parked<BF16, NT> A3P;                // gelu'(a3) (or a3) waits here for the backward chain in half the registers;
+                                         // n^ is recovered from its own fragments F, which the heads keep alive anyway
+#else
     f32x4 a3[NT], nh[NT];
+#endif
     float mu1, r1;
     {
+#if ENF_K3_PARK
+      f32x4 a3[NT], nh[NT];
+#endif
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
       make_frags<BF16, KB>(F, acc);
@@ -360,10 +394,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
       for (int t = 0; t < NT; ++t) a3[t] = rowvec(c_bf, t, quad);
       panel_gemm<KB, NT, BF16, ST_GB>(a3, F, P, ring, pF, pGB, true, lane);
+#if ENF_K3_FUSED_GELU
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) nh[t] = a3[t];
+      gelu_fg_tiles<NT>(nh, a3);            // nh = gelu(a3); a3 <- gelu'(a3), all the backward needs of it
+#else
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) nh[t][i] = gelu_f(a3[t][i]);
+        K3_SCHED_FENCE();
+      }
+#endif
       ln_stats<NT>(nh, mu1, r1);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -371,6 +413,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int i = 0; i < 4; ++i) nh[t][i] = (nh[t][i] - mu1) * r1;
       make_frags<BF16, KB>(F, nh);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_NH], srow, D, F, quad);
+#if ENF_K3_PARK
+      A3P.park(a3);
+#endif
     }
     BSTAMP(2);
     f32x4 dnh[NT];                       // d n^ accumulated over heads
@@ -379,9 +424,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 
 #pragma unroll
     for (int h = 0; h < H; ++h) {
+#if ENF_K3_PARK
+      f32x4 v[NT];
+      Parked<BF16, NT> OPG;
+      {
+        f32x4 opgf[NT];
+        gb_panel_flip<D, BF16, ST_DD>(v, opgf, F, P, ring, pGB + h * PANEL_GB, pM, c_bgb + 2 * h * D, zv + H * D + h * D,
+                                      lane, col, quad);
+        OPG.park(opgf);
+      }
+#else
       f32x4 v[NT], opgf[NT];
       gb_panel_flip<D, BF16, ST_DD>(v, opgf, F, P, ring, pGB + h * PANEL_GB, pM, c_bgb + 2 * h * D, zv + H * D + h * D,
                                     lane, col, quad);
+#endif
       BSTAMP(3 + 6 * h);
       f32x4 a5[NT];
       {
@@ -395,10 +451,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       BSTAMP(4 + 6 * h);
       // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
       float mu2, r2;
+#if ENF_K3_FUSED_GELU
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) v[t] = a5[t];
+      gelu_fg_tiles<NT>(v, a5);             // v = gelu(a5); a5 <- gelu'(a5)
+#else
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[t][i] = gelu_f(a5[t][i]);
+        K3_SCHED_FENCE();
+      }
+#endif
       ln_stats<NT>(v, mu2, r2);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -427,9 +491,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int i = 0; i < 4; ++i) { dy[t][i] *= ah; s1 += dy[t][i]; s2 = fmaf(dy[t][i], v[t][i], s2); }
       const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
+        // the pre-activation goes through an opaque copy: otherwise hipcc keeps x^2, the exponent and the sigmoid of
+        // all 32 elements alive from gelu() above to share them with gelu'() here -- ~100 registers, all spilled
+        K3_OPAQUE(a5[t]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * gelu_grad_f(a5[t][i]);   // d a5
+        for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * (ENF_K3_FUSED_GELU ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
+        K3_SCHED_FENCE();     // one tile's transcendental chain at a time: interleaving all 32 costs ~100 live registers
+      }
       BSTAMP(5 + 6 * h);
       // d v = AM d a5 (transposed, feeds d gamma / d beta) and its flipped twin:
       // d v0[d] += sum_n dv[n][d] (1 + gamma[n][d])
@@ -442,7 +511,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true>(
             v, FA, P, ring, gM, gGB + h * PANEL_GG, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
             [&](int mt, const f32x4& af) {
-              dV0_add(h, mt, af[0] * opgf[mt][0] + af[1] * opgf[mt][1] + af[2] * opgf[mt][2] + af[3] * opgf[mt][3]);
+#if ENF_K3_PARK
+              const f32x4 og = OPG.get(mt);
+#else
+              const f32x4 og = opgf[mt];
+#endif
+              dV0_add(h, mt, af[0] * og[0] + af[1] * og[1] + af[2] * og[2] + af[3] * og[3]);
             });                                                                                               // v <- d v
       }
       BSTAMP(6 + 6 * h);
@@ -490,14 +564,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
+#if ENF_K3_PARK
+        const f32x4 nht = Parked<BF16, NT>{F}.get(t);
+#else
+        const f32x4 nht = nh[t];
+#endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s1 += dnh[t][i]; s2 = fmaf(dnh[t][i], nh[t][i], s2); }
+        for (int i = 0; i < 4; ++i) { s1 += dnh[t][i]; s2 = fmaf(dnh[t][i], nht[i], s2); }
+      }
       const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
+#if ENF_K3_PARK
+        const f32x4 nht = Parked<BF16, NT>{F}.get(t);
+        f32x4 a3t = A3P.get(t);
+        K3_OPAQUE(a3t);
+#else
+        const f32x4 nht = nh[t], a3t = a3[t];
+#endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dnh[t][i] = r1 * (dnh[t][i] - m1 - nh[t][i] * m2) * gelu_grad_f(a3[t][i]);   // d a3
+        for (int i = 0; i < 4; ++i) dnh[t][i] = r1 * (dnh[t][i] - m1 - nht[i] * m2) * (ENF_K3_FUSED_GELU ? a3t[i] : gelu_grad_f(a3t[i]));   // d a3
+        K3_SCHED_FENCE();
+      }
       make_frags<BF16, KB>(F, dnh);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA3], srow, D, F, quad);
       f32x4 acc[NT];
