@@ -105,12 +105,27 @@ template <bool BF16, int KB> DEV void relu_frags(Frags<BF16, KB>& F) {
 
 // acc[mt] += W^T[16 mt .., :] X for MTS out-tiles whose fragments start at `lds`.
 // Panel order (enf_pack.hip): bf16 [mt][blk][lane] x 16 B; fp32 [mt][in-tile][lane] x 16 B.
-template <bool BF16, int KB, int MTS>
-DEV void gemm_stage(f32x4* acc, const Frags<BF16, KB>& F, const char* lds, int lane) {
+// INIT: how the accumulators start.  INIT_ACC: the caller initialised them; INIT_ZERO: from zero (the asm stage
+// feeds C = 0 to each accumulator's first MFMA: no v_mov, and the registers are not live before the stage);
+// INIT_BIAS: from the per-row vector `bias` (fp32 in LDS, tile 0 of this stage), loaded inside the asm stage.
+enum { INIT_ACC = 0, INIT_ZERO = 1, INIT_BIAS = 2 };
+template <bool BF16, int KB, int MTS, int INIT = INIT_ACC>
+DEV void gemm_stage(f32x4* acc, const Frags<BF16, KB>& F, const char* lds, int lane, const float* bias = nullptr) {
   if constexpr (BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::available) {
     // hand-scheduled stage: NBUF fragment reads in flight, MFMAs round-robin over the accumulators
-    GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::run(acc, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(lds) + (lane << 4)));
+    using G = GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>;
+    const unsigned a = (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(lds) + (lane << 4));
+    if constexpr (INIT == INIT_ZERO) G::run_zero(acc, F.f, a);
+    else if constexpr (INIT == INIT_BIAS) G::run_bias(acc, F.f, a, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<float*>(bias) + 4 * (lane >> 4)));
+    else G::run(acc, F.f, a);
     return;
+  }
+  if constexpr (INIT == INIT_ZERO) {
+#pragma unroll
+    for (int mt = 0; mt < MTS; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else if constexpr (INIT == INIT_BIAS) {
+#pragma unroll
+    for (int mt = 0; mt < MTS; ++mt) acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * (lane >> 4));
   }
 #pragma unroll
   for (int mt = 0; mt < MTS; ++mt) {
@@ -342,25 +357,25 @@ template <int KBIN, int MTOUT, bool BF16> struct PanelCfg {
 // `next`, NEXT_BYTES long; NO_STAGE = nothing follows) streams into the other ring slot; one
 // wait + one barrier per stage publish it.  `panel` / `next` are blob byte offsets (wave-uniform).
 // `active` (wave-uniform) lets a wave without work keep the staging / barrier cadence.
-template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES>
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES, int INIT = INIT_ACC>
 DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned next,
-                    bool active, int lane) {
+                    bool active, int lane, const float* bias = nullptr) {
   using C = PanelCfg<KBIN, MTOUT, BF16>;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
     stage_open(P);
     if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
-    if (active) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane);
+    if (active) gemm_stage<BF16, KBIN, C::MTS, INIT>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane, bias + 16 * sp * C::MTS);
     stage_close(P);
   }
 }
 
 // panel_gemm that additionally hands every out-tile's FLIPPED product to `flip(tile, acc)`
 // (acc starts at flip_init(tile)); TRANS = false skips the transposed product.
-template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW, bool TRANS, typename InitFn, typename FlipFn>
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW, bool TRANS, int INIT = INIT_ACC, typename InitFn, typename FlipFn>
 DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel,
-                         unsigned next, int lane, InitFn&& flip_init, FlipFn&& flip) {
+                         unsigned next, int lane, InitFn&& flip_init, FlipFn&& flip, const float* bias = nullptr) {
   using C = PanelCfg<KBIN, MTOUT, BF16>;
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
@@ -373,11 +388,16 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
       f32x4 af[C::MTS];
 #pragma unroll
       for (int mt = 0; mt < C::MTS; ++mt) af[mt] = flip_init(sp * C::MTS + mt);
-      GemmStageAsm<KBIN, C::MTS, ENF_ASM_LITE != 0>::run_both(&acc[sp * C::MTS], af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
+      using G = GemmStageAsm<KBIN, C::MTS, ENF_ASM_LITE != 0>;
+      const unsigned a = (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4));
+      if constexpr (INIT == INIT_ZERO) G::run_both_zero(&acc[sp * C::MTS], af, F.f, a);
+      else if constexpr (INIT == INIT_BIAS)
+        G::run_both_bias(&acc[sp * C::MTS], af, F.f, a, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<float*>(bias) + 16 * sp * C::MTS + 4 * (lane >> 4)));
+      else G::run_both(&acc[sp * C::MTS], af, F.f, a);
 #pragma unroll
       for (int mt = 0; mt < C::MTS; ++mt) flip(sp * C::MTS + mt, af[mt]);
     } else {
-      if constexpr (TRANS) gemm_stage<BF16, KBIN, C::MTS>(&acc[sp * C::MTS], F, slot, lane);
+      if constexpr (TRANS) gemm_stage<BF16, KBIN, C::MTS, INIT>(&acc[sp * C::MTS], F, slot, lane, bias + 16 * sp * C::MTS);
 #pragma unroll
       for (int mt = 0; mt < C::MTS; ++mt) {
         f32x4 af = flip_init(sp * C::MTS + mt);

@@ -129,8 +129,6 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
     else if (next != NO_STAGE) stage_issue<NEXT_BYTES>(P.rs, next, ring + (P.cur ^ 1) * STAGE_MAX, P.wave, lane);
     const char* slot = ring + P.cur * STAGE_MAX;
     f32x4 t[MTS];
-#pragma unroll
-    for (int j = 0; j < MTS; ++j) t[j] = rowvec(bias, sp * MTS + j, quad);
     constexpr bool ASM = BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::available && MTS == 8;
     if constexpr (ASM) {
       // transposed product of all 8 tiles + flipped product of the 4 gamma tiles {0,1,4,5} from one fragment read
@@ -140,10 +138,13 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
         const float bc = 1.0f + bias[16 * (sp * MTS + 4 * (j >> 1) + (j & 1)) + col];
         af[j] = f32x4{bc, bc, bc, bc};
       }
-      GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::run_gb(t, af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)));
+      GemmStageAsm<KB, MTS, ENF_ASM_LITE != 0>::run_gb_bias(t, af, F.f, (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4)),
+                                                            (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<float*>(bias) + 16 * sp * MTS + 4 * quad));
 #pragma unroll
       for (int j = 0; j < 4; ++j) opgf[2 * (sp * (MTS / 4) + (j >> 1)) + (j & 1)] = af[j];
     } else {
+#pragma unroll
+      for (int j = 0; j < MTS; ++j) t[j] = rowvec(bias, sp * MTS + j, quad);
       gemm_stage<BF16, KB, MTS>(t, F, slot, lane);
     }
 #pragma unroll
@@ -345,9 +346,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acq, lane, quad);
       make_frags<BF16, KB>(F, acc);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
-      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pQ1, pV1, true, lane);
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pQ1, pV1, true, lane, c_bq1);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float s = 0.f;
@@ -379,9 +378,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EV], srow, D, F, quad);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bv1, t, quad);
-      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, pV1, pF, true, lane);
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pV1, pF, true, lane, c_bv1);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -391,9 +388,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         }
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) a3[t] = rowvec(c_bf, t, quad);
-      panel_gemm<KB, NT, BF16, ST_GB>(a3, F, P, ring, pF, pGB, true, lane);
+      panel_gemm<KB, NT, BF16, ST_GB, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, pGB, true, lane, c_bf);
 #if ENF_K3_FUSED_GELU
 #pragma unroll
       for (int t = 0; t < NT; ++t) nh[t] = a3[t];
@@ -444,9 +439,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         Frags<BF16, KB> FV;
         make_frags<BF16, KB>(FV, v);
         if (swrite) store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h], srow, D, FV, quad);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) a5[t] = rowvec(c_bm, t, quad);
-        panel_gemm<KB, NT, BF16, ST_DD>(a5, FV, P, ring, pM, gM, true, lane);
+        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a5, FV, P, ring, pM, gM, true, lane, c_bm);
       }
       BSTAMP(4 + 6 * h);
       // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
@@ -506,9 +499,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         Frags<BF16, KB> FA;
         make_frags<BF16, KB>(FA, dy);
         if (swrite) store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 1], srow, D, FA, quad);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true>(
+        panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true, INIT_ZERO>(
             v, FA, P, ring, gM, gGB + h * PANEL_GG, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
             [&](int mt, const f32x4& af) {
 #if ENF_K3_PARK
@@ -590,18 +581,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, dnh);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA3], srow, D, F, quad);
       f32x4 acc[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, gF, gV1, true, lane);                                     // d g1
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO>(acc, F, P, ring, gF, gV1, true, lane);                  // d g1
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = ((relu_mask >> (4 * t + i)) & 1u) ? acc[t][i] : 0.f;             // d a2
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA2], srow, D, F, quad);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      panel_gemm<KB, NT, BF16, ST_DD>(acc, F, P, ring, gV1, pQ1, true, lane);                                    // d E_v
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO>(acc, F, P, ring, gV1, pQ1, true, lane);                 // d E_v
       f32x4 Ev[NT];
       rff_embed<D, BF16>(Ev, inv, c_acv, lane, quad);                                                            // recomputed
       f32x4 dT[TT];
@@ -621,15 +608,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, E);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EQ], srow, D, F, quad);
       f32x4 acc[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
       float dl[H][4];                     // dlogit of the 4 queries this lane's flipped rows hold
 #pragma unroll
       for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dl[h][i] = __shfl(dlogit[h], (quad << 4) | (4 * quad + i), 64);
       const bool more = ti + 1 < my_tiles;
-      panel_gemm_flip<KB, NT, BF16, ST_DD, NW, true>(
+      panel_gemm_flip<KB, NT, BF16, ST_DD, NW, true, INIT_BIAS>(
           acc, F, P, ring, pQ1, gQ1, lane,
           [&](int mt) { const float bc = c_bq1[16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
           [&](int mt, const f32x4& af) {
@@ -637,7 +622,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
             for (int h = 0; h < H; ++h)
               dU_add(h, mt, dl[h][0] * fmaxf(af[0], 0.f) + dl[h][1] * fmaxf(af[1], 0.f) + dl[h][2] * fmaxf(af[2], 0.f) +
                                 dl[h][3] * fmaxf(af[3], 0.f));
-          });                                                                                                    // a1
+          }, c_bq1);                                                                                             // a1
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         f32x4 dh = {0.f, 0.f, 0.f, 0.f};
@@ -653,9 +638,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       Frags<BF16, KB> FA;
       make_frags<BF16, KB>(FA, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA1], srow, D, FA, quad);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      panel_gemm<KB, NT, BF16, ST_DD>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, lane);                 // d E_q
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, lane);   // d E_q
       f32x4 dT[TT];
       rff_embed_bwd<D>(dT, acc, E);
       Frags<BF16, D / 64> FT;

@@ -16,30 +16,42 @@ SHAPES = [(4, 8, 8), (2, 4, 6), (2, 8, 8)]        # (KB, MTS, NBUF)
 TAIL_NOPS = 11     # MFMA result -> first compiler VALU reader: wait states inside the string
 
 
-def emit(KB, MTS, NBUF, flip):
+def _acc_ops(MTS, init):
+    """operand constraints of the accumulators for an init mode: 'acc' = read-modify-write (caller initialised),
+    'zero' = written by the first MFMA with C = 0, 'bias' = loaded from LDS inside the statement"""
+    con = "+v" if init == "acc" else "=&v"
+    return [f'[a{m}] "{con}"(acc[{m}])' for m in range(MTS)]
+
+
+def _bias_reads(MTS):
+    return [f"ds_read_b128 %[a{mt}], %[bias] offset:{64 * mt}" for mt in range(MTS)]
+
+
+def emit(KB, MTS, NBUF, init):
     n = KB * MTS
     order = [(mt, blk) for blk in range(KB) for mt in range(MTS)]    # consecutive MFMAs: different accumulators
     off = lambda mt, blk: (mt * KB + blk) * 1024
     L = []
     L.append("s_waitcnt lgkmcnt(0)")              # SMEM returns out of order: start from a clean counter
+    if init == "bias":
+        L += _bias_reads(MTS)                      # in-order LDS returns: done before the first fragment is
     for i in range(min(NBUF, n)):
         L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i])}")
     for i, (mt, blk) in enumerate(order):
         inflight = min(i + NBUF, n) - i            # reads issued and not yet consumed, this one included
         L.append(f"s_waitcnt lgkmcnt({inflight - 1})")
-        a, b = f"%[s{i % NBUF}]", f"%[b{blk}]"
-        if flip:
-            a, b = b, a
-        L.append(f"v_mfma_f32_16x16x32_bf16 %[a{mt}], {a}, {b}, %[a{mt}]")
+        c = "0" if (init == "zero" and blk == 0) else f"%[a{mt}]"
+        L.append(f"v_mfma_f32_16x16x32_bf16 %[a{mt}], %[s{i % NBUF}], %[b{blk}], {c}")
         if i + NBUF < n:
             L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i + NBUF])}")
     L.append(f"s_nop {TAIL_NOPS}")
     body = "\n".join(f'      "{x}\\n\\t"' for x in L)
-    outs = ", ".join([f'[a{m}] "+v"(acc[{m}])' for m in range(MTS)] + [f'[s{j}] "=&v"(s{j})' for j in range(NBUF)])
-    ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'])
-    name = "run_flip" if flip else "run"
+    outs = ", ".join(_acc_ops(MTS, init) + [f'[s{j}] "=&v"(s{j})' for j in range(NBUF)])
+    ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'] + (['[bias] "v"(bias_addr)'] if init == "bias" else []))
+    name = {"acc": "run", "zero": "run_zero", "bias": "run_bias"}[init]
     decl = ", ".join(f"s{j}" for j in range(NBUF))
-    return f"""  static __device__ __forceinline__ void {name}(f32x4* acc, const bf16x8* B, unsigned lds_addr) {{
+    extra = ", unsigned bias_addr" if init == "bias" else ""
+    return f"""  static __device__ __forceinline__ void {name}(f32x4* acc, const bf16x8* B, unsigned lds_addr{extra}) {{
     f32x4 {decl};
     asm volatile(
 {body}
@@ -49,7 +61,7 @@ def emit(KB, MTS, NBUF, flip):
 """
 
 
-def emit_both(KB, MTS, NBUF, mask, name):
+def emit_both(KB, MTS, NBUF, mask, name, init="acc"):
     """Transposed product into acc[mt] AND, for the out-tiles in `mask`, the flipped product (operands swapped:
     rows = the wave's columns) into af[.] from the same fragment read."""
     n = KB * MTS
@@ -57,25 +69,30 @@ def emit_both(KB, MTS, NBUF, mask, name):
     off = lambda mt, blk: (mt * KB + blk) * 1024
     fl = [mt for mt in range(MTS) if mask >> mt & 1]
     L = ["s_waitcnt lgkmcnt(0)"]
+    if init == "bias":
+        L += _bias_reads(MTS)
     for i in range(min(NBUF, n)):
         L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i])}")
     for i, (mt, blk) in enumerate(order):
         inflight = min(i + NBUF, n) - i
         L.append(f"s_waitcnt lgkmcnt({inflight - 1})")
-        L.append(f"v_mfma_f32_16x16x32_bf16 %[a{mt}], %[s{i % NBUF}], %[b{blk}], %[a{mt}]")
+        c = "0" if (init == "zero" and blk == 0) else f"%[a{mt}]"
+        L.append(f"v_mfma_f32_16x16x32_bf16 %[a{mt}], %[s{i % NBUF}], %[b{blk}], {c}")
         if mt in fl:
             L.append(f"v_mfma_f32_16x16x32_bf16 %[f{fl.index(mt)}], %[b{blk}], %[s{i % NBUF}], %[f{fl.index(mt)}]")
         if i + NBUF < n:
             L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i + NBUF])}")
     L.append(f"s_nop {TAIL_NOPS}")
     body = "\n".join(f'      "{x}\\n\\t"' for x in L)
-    outs = ", ".join([f'[a{m}] "+v"(acc[{m}])' for m in range(MTS)] + [f'[f{j}] "+v"(af[{j}])' for j in range(len(fl))] +
+    outs = ", ".join(_acc_ops(MTS, init) + [f'[f{j}] "+v"(af[{j}])' for j in range(len(fl))] +
                      [f'[s{j}] "=&v"(s{j})' for j in range(NBUF)])
-    ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'])
+    ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'] + (['[bias] "v"(bias_addr)'] if init == "bias" else []))
     decl = ", ".join(f"s{j}" for j in range(NBUF))
+    name = name + {"acc": "", "zero": "_zero", "bias": "_bias"}[init]
+    extra = ", unsigned bias_addr" if init == "bias" else ""
     return f"""  // af[j] <-> out-tile {fl}
   static constexpr int {name}_nflip = {len(fl)};
-  static __device__ __forceinline__ void {name}(f32x4* acc, f32x4* af, const bf16x8* B, unsigned lds_addr) {{
+  static __device__ __forceinline__ void {name}(f32x4* acc, f32x4* af, const bf16x8* B, unsigned lds_addr{extra}) {{
     f32x4 {decl};
     asm volatile(
 {body}
@@ -97,9 +114,11 @@ def main(path):
             nb0 = min(NBUF, 4) if lite else NBUF
             out.append(f"template <> struct GemmStageAsm<{KB}, {MTS}, {'true' if lite else 'false'}> {{")
             out.append("  static constexpr bool available = true;")
-            out.append(emit(KB, MTS, nb0, False))
+            for init in ("acc", "zero", "bias"):
+                out.append(emit(KB, MTS, nb0, init))
             for mask, name, nb in BOTH.get((KB, MTS), []):
-                out.append(emit_both(KB, MTS, min(nb, 4) if lite else nb, mask, name))
+                for init in ("acc", "zero", "bias"):
+                    out.append(emit_both(KB, MTS, min(nb, 4) if lite else nb, mask, name, init))
             out.append("};\n")
     open(path, "w").write("\n".join(out))
 
