@@ -41,6 +41,9 @@
 #else
 #define K3_OPAQUE(x) do {} while (0)
 #endif
+#ifndef ENF_K3_EARLY_DY
+#define ENF_K3_EARLY_DY 0
+#endif
 #ifndef ENF_K3_PARK
 #define ENF_K3_PARK 1
 #endif
@@ -302,6 +305,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // every lane owns its slots: plain read-modify-write (an LDS float atomic costs ~1000 cycles here)
   auto dU_add = [&](int h, int t, float v) { lacc[(h * NT + t) * 64] += v; };
   auto dV0_add = [&](int h, int t, float v) { lacc[((H + h) * NT + t) * 64] += v; };
+  // flush NT partial sums of one head at once: all reads, then all adds, then all writes (one LDS round trip)
+  auto lacc_flush = [&](int slot0, const float (&part)[NT]) {
+    float cur[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cur[t] = lacc[(slot0 + t) * 64];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) lacc[(slot0 + t) * 64] = cur[t] + part[t];
+  };
   auto dU_get = [&](int h, int t) { return lacc[(h * NT + t) * 64]; };
   auto dV0_get = [&](int h, int t) { return lacc[((H + h) * NT + t) * 64]; };
 #else
@@ -442,6 +453,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a5, FV, P, ring, pM, gM, true, lane, c_bm);
       }
       BSTAMP(4 + 6 * h);
+      // d ybar of this head: issued first, the gelu / LayerNorm arithmetic below hides the L2 round trip
+      f32x4 dy[NT];
+#if ENF_K3_EARLY_DY
+      {
+        const float* dyrow = A.dybar + qrow * (H * D) + h * D;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t + 4 * quad);
+      }
+#endif
       // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
       float mu2, r2;
 #if ENF_K3_FUSED_GELU
@@ -462,12 +482,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[t][i] = (v[t][i] - mu2) * r2;
       // d n~ = att * d ybar ;  d att = d ybar . n~ ;  softmax backward with the forward's lse / delta
-      f32x4 dy[NT];
+#if !ENF_K3_EARLY_DY
       {
         const float* dyrow = A.dybar + qrow * (H * D) + h * D;
 #pragma unroll
         for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t + 4 * quad);
       }
+#endif
       float s0 = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -499,6 +520,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         Frags<BF16, KB> FA;
         make_frags<BF16, KB>(FA, dy);
         if (swrite) store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 1], srow, D, FA, quad);
+        float part[NT];
         panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true, INIT_ZERO>(
             v, FA, P, ring, gM, gGB + h * PANEL_GG, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
             [&](int mt, const f32x4& af) {
@@ -507,8 +529,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #else
               const f32x4 og = opgf[mt];
 #endif
-              dV0_add(h, mt, af[0] * og[0] + af[1] * og[1] + af[2] * og[2] + af[3] * og[3]);
+              part[mt] = af[0] * og[0] + af[1] * og[1] + af[2] * og[2] + af[3] * og[3];
             });                                                                                               // v <- d v
+#if ENF_K3_LDSACC
+        lacc_flush((H + h) * NT, part);
+#else
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) dV0_add(h, mt, part[mt]);
+#endif
       }
       BSTAMP(6 + 6 * h);
       // FiLM backward: d gamma = d v * v0; d beta = d v.
@@ -614,15 +642,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) dl[h][i] = __shfl(dlogit[h], (quad << 4) | (4 * quad + i), 64);
       const bool more = ti + 1 < my_tiles;
+      float upart[H][NT];
       panel_gemm_flip<KB, NT, BF16, ST_DD, NW, true, INIT_BIAS>(
           acc, F, P, ring, pQ1, gQ1, lane,
           [&](int mt) { const float bc = c_bq1[16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
           [&](int mt, const f32x4& af) {
+            const float r0 = relu_f(af[0]), r1 = relu_f(af[1]), r2 = relu_f(af[2]), r3 = relu_f(af[3]);
 #pragma unroll
-            for (int h = 0; h < H; ++h)
-              dU_add(h, mt, dl[h][0] * fmaxf(af[0], 0.f) + dl[h][1] * fmaxf(af[1], 0.f) + dl[h][2] * fmaxf(af[2], 0.f) +
-                                dl[h][3] * fmaxf(af[3], 0.f));
+            for (int h = 0; h < H; ++h) upart[h][mt] = dl[h][0] * r0 + dl[h][1] * r1 + dl[h][2] * r2 + dl[h][3] * r3;
           }, c_bq1);                                                                                             // a1
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+#if ENF_K3_LDSACC
+        lacc_flush(h * NT, upart[h]);
+#else
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) dU_add(h, mt, upart[h][mt]);
+#endif
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         f32x4 dh = {0.f, 0.f, 0.f, 0.f};
