@@ -11,7 +11,8 @@ int enf_launch_prologue_bwd(const EnfDims&, const EnfLayout&, const char*, const
 int enf_launch_pair_fwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, float*, float*,
                         char*, float*, char*, int, int, hipStream_t);
 int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, const float*,
-                        const float*, const float*, float*, void* const*, hipStream_t);
+                        const float*, const float*, float*, void* const*, const char*, const float*, hipStream_t);
+int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
 int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
                     int, hipStream_t);
 }
@@ -129,7 +130,10 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
     return rc;
   if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, st))) return rc;
   if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
-  if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr, st))) return rc;
+  const bool zb = enf_use_zfold_bwd(m);
+  if (zb && (rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, st))) return rc;
+  if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr,
+                                zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, st))) return rc;
   if ((rc = enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st))) return rc;
   return ENF_OK;
 }
@@ -155,6 +159,15 @@ int enf_zfold_mode() {
   return g_zfold_mode;
 }
 extern "C" void enf_set_zfold(int mode) { g_zfold_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
+static int g_zfold_bwd_mode = -2;
+int enf_zfold_bwd_mode() {
+  if (g_zfold_bwd_mode == -2) {
+    const char* e = getenv("ENF_ZFOLD_BWD");
+    g_zfold_bwd_mode = !e ? -1 : (e[0] == '0' ? 0 : 1);
+  }
+  return g_zfold_bwd_mode;
+}
+extern "C" void enf_set_zfold_bwd(int mode) { g_zfold_bwd_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
 
 extern "C" size_t enf_pair_scratch_bytes(const EnfDesc* d) {
   if (enf_check_desc(d)) return 0;
@@ -191,5 +204,5 @@ extern "C" int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bst
       if (!store[i]) return ENF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dlt, 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
-  return enf_launch_pair_bwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, lse, dybar, delta, dlt, store, st);
+  return enf_launch_pair_bwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, lse, dybar, delta, dlt, store, nullptr, nullptr, st);
 }

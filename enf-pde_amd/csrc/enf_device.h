@@ -396,6 +396,20 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
       else G::run_both(&acc[sp * C::MTS], af, F.f, a);
 #pragma unroll
       for (int mt = 0; mt < C::MTS; ++mt) flip(sp * C::MTS + mt, af[mt]);
+    } else if constexpr (!TRANS && BF16 && ENF_ASM_GEMM && GemmStageAsm<KBIN, C::MTS, ENF_ASM_LITE != 0>::available) {
+      // flipped product only
+      using G = GemmStageAsm<KBIN, C::MTS, ENF_ASM_LITE != 0>;
+      const unsigned a = (unsigned)(uintptr_t)(lds_ptr_t)(const_cast<char*>(slot) + (lane << 4));
+      f32x4 af[C::MTS];
+      if constexpr (INIT == INIT_ZERO) {
+        G::run_flip_zero(af, F.f, a);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < C::MTS; ++mt) af[mt] = flip_init(sp * C::MTS + mt);
+        G::run_flip(af, F.f, a);
+      }
+#pragma unroll
+      for (int mt = 0; mt < C::MTS; ++mt) flip(sp * C::MTS + mt, af[mt]);
     } else {
       if constexpr (TRANS) gemm_stage<BF16, KBIN, C::MTS, INIT>(&acc[sp * C::MTS], F, slot, lane, bias + 16 * sp * C::MTS);
 #pragma unroll

@@ -98,6 +98,8 @@ struct EnfLayout {
   size_t p_wbmt;                        // H x (D x D): [h][k][i] = sum_j Wbeta_h[i][j] AM[j][k]
   size_t p_cb;                          // H x D:       [h][k]    = sum_j bbeta_h[j] AM[j][k] + bm[k]
   size_t p_opbg;                        // H x D:       [h][j]    = 1 + bgamma_h[j]
+  size_t p_wbm;                         // H x (D x D): p_wbmt transposed ([h][i][k]), for the backward-orientation panels
+  size_t awg;                           // H forward panels (D x D): gamma half of inv_emb_to_v.Dense_1, A[j][i] = Wgamma_h[i][j]
   size_t total;
 };
 
@@ -134,6 +136,7 @@ inline EnfLayout enf_layout(const EnfDims& m) {
   L.p_wf1 = take(f * HD * HD); L.p_tmp = take(f * HD * HD); L.p_o4 = take(f * D * OP);
   L.p_mxw = take(f * D * D); L.p_mxb = take(f * D);
   L.p_wbmt = take(f * H * D * D); L.p_cb = take(f * H * D); L.p_opbg = take(f * H * D);
+  L.p_wbm = take(f * H * D * D); L.awg = take(H * enf_panel_bytes(D, D, bf));
   L.total = o;
   return L;
 }
@@ -162,6 +165,16 @@ inline bool enf_use_zfold(const EnfDims& m) {
 
 ENF_HD inline size_t enf_wzu_bytes(int H, int D) { return (size_t)(D / 32) * 4 * H * 16; }
 
+// Backward counterpart (enf_pair_bwd_kernel<.., ZF = true>): one workgroup per latent, its 8 waves take 8 query
+// tiles at a time, so the per-latent matrices W_zh (both orientations) stream through the LDS ring shared by the
+// workgroup.  Needs enough latents to fill the chip.  ENF_ZFOLD_BWD=0/1 / enf_set_zfold_bwd() force the choice.
+int enf_zfold_bwd_mode();
+inline bool enf_use_zfold_bwd(const EnfDims& m) {
+  const int mode = enf_zfold_bwd_mode();
+  if (mode >= 0) return mode == 1;
+  return (long long)m.B * m.Z >= 192;
+}
+
 struct EnfWorkspace {
   size_t lt;        // B*Z*lt_stride floats: latent table
   size_t an;        // B*Z*(D + D + 2) floats: stem output, a_norm, LN mean/rstd (prologue backward)
@@ -174,6 +187,7 @@ struct EnfWorkspace {
   size_t dlt;       // B*Z*lt_stride floats: gradient of the latent table (backward)
   size_t wz;        // B*Z*H packed D x D panels: per-latent mixer-input matrices (z-fold forward only)
   size_t wzb;       // B*Z*H*D floats: their bias vectors
+  size_t wzt;       // B*Z*H x [forward | backward] packed D x D panels of W_zh (z-fold backward)
   size_t wzu;       // B*Z x (D/32 * 4 * H) x 16 B: the logit vectors u_zh as bf16 A-operand rows (z-fold, bf16 mode)
   size_t total;
 };
@@ -193,9 +207,10 @@ inline EnfWorkspace enf_workspace(const EnfDims& m) {
   W.delta = take(f * BN * m.H);
   W.tail_act = take(f * BN * (2 * m.HD + 2 * m.D + 2));
   W.dlt = take(f * BZ * enf_lt_stride(m.H, m.D));
-  const bool zf = enf_use_zfold(m);
-  W.wz = take(zf ? BZ * m.H * enf_panel_bytes(m.D, m.D, m.bf16) : 0);
-  W.wzb = take(zf ? f * BZ * m.HD : 0);
+  const bool zf = enf_use_zfold(m), zb = enf_use_zfold_bwd(m);
+  W.wz = take(zf || zb ? BZ * m.H * enf_panel_bytes(m.D, m.D, m.bf16) : 0);
+  W.wzb = take(zf || zb ? f * BZ * m.HD : 0);
+  W.wzt = take(zb ? BZ * m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) : 0);
   W.wzu = take(zf ? BZ * enf_wzu_bytes(m.H, m.D) : 0);
   W.total = o;
   return W;

@@ -96,10 +96,16 @@ __global__ void pack_panel_kernel(void* dst, const float* W, int ldw, int R, int
   else reinterpret_cast<float*>(dst)[e] = v;
 }
 
+// gamma half of one head out of the [g g b b]-interleaved D x 2HD matrix: dst[i][j] = Wgamma_h[i][j]
+__global__ void gamma_extract_kernel(float* dst, const float* agb, int h, int H, int D) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j < D) dst[(size_t)i * D + j] = agb[(size_t)i * 2 * H * D + h * 2 * D + 64 * (j >> 5) + (j & 31)];
+}
+
 // latent-independent parts of the per-latent fold W_zh = (Wgamma_h diag(v0) + Wbeta_h) AM (enf_wz.hip):
 //   wbmt[h][k][i] = sum_j Wbeta_h[i][j] AM[j][k];  cb[h][k] = sum_j bbeta_h[j] AM[j][k] + bm[k];  opbg[h][j] = 1 + bgamma_h[j]
 // agb / bgb are in the [g g b b] interleaved column order of reorder_gb_kernel.
-__global__ void wz_const_kernel(float* wbmt, float* cb, float* opbg, const float* agb, const float* bgb, const float* am,
+__global__ void wz_const_kernel(float* wbmt, float* wbm, float* cb, float* opbg, const float* agb, const float* bgb, const float* am,
                                 const float* bm, int H, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y, h = blockIdx.z;
   if (i >= D) return;
@@ -108,6 +114,7 @@ __global__ void wz_const_kernel(float* wbmt, float* cb, float* opbg, const float
   float s = 0.f;
   for (int j = 0; j < D; ++j) s = fmaf(agb[(size_t)i * HD2 + bcol(j)], am[(size_t)j * D + k], s);
   wbmt[((size_t)h * D + k) * D + i] = s;
+  wbm[((size_t)h * D + i) * D + k] = s;
   if (i == 0) {
     float c = bm[k];
     for (int j = 0; j < D; ++j) c = fmaf(bgb[bcol(j)], am[(size_t)j * D + k], c);
@@ -158,9 +165,15 @@ static int pack_pair_panels(hipStream_t st, char* blob, const EnfLayout& L, cons
   if ((rc = pack_panel(st, blob, L.gcq, coefq, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
   if ((rc = pack_panel(st, blob, L.gcv, coefv, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
-  hipLaunchKernelGGL(wz_const_kernel, dim3((D + 63) / 64, D, H), dim3(64), 0, st, F(L.p_wbmt), F(L.p_cb), F(L.p_opbg), agb,
+  hipLaunchKernelGGL(wz_const_kernel, dim3((D + 63) / 64, D, H), dim3(64), 0, st, F(L.p_wbmt), F(L.p_wbm), F(L.p_cb), F(L.p_opbg), agb,
                      F(L.bgb), am, F(L.bm), H, D);
-  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+  if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
+  for (int h = 0; h < H; ++h) {      // gamma-only forward panels (z-fold backward: flipped 1 + gamma for d v0)
+    hipLaunchKernelGGL(gamma_extract_kernel, dim3((D + 63) / 64, D), dim3(64), 0, st, F(L.p_tmp), agb, h, H, D);
+    if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
+    if ((rc = pack_panel(st, blob, L.awg + (size_t)h * enf_panel_bytes(D, D, bf), F(L.p_tmp), D, D, D, 0, bf))) return rc;
+  }
+  return ENF_OK;
 }
 
 // Pack ONLY what the pair kernels (enf_pair_forward / enf_pair_backward) read, from the "effective"

@@ -60,6 +60,7 @@ struct PairBwdArgs {
   const float* lse; const float* dybar; const float* delta;
   float* dlt;
   void* store[ENF_NUM_STORE(2)];        // ENF_S_* buffers (STORE instantiation only)
+  const char* wzt; const float* wzb;    // ZF only: per (latent, head) [forward | backward] panels of W_zh, and c_zh
   int B, N, Z, dx, inv, use_window, nsplit;
 };
 
@@ -242,8 +243,13 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
   }
 }
 
-template <int D, int H, bool BF16, bool STORE>
+// ZF (z-fold backward, no STORE): ONE latent per workgroup, the 8 waves take 8 query tiles per sweep step, and per
+// head the chain uses the per-latent fold of enf_wz.hip:  a5 = W_zh^T n + c_zh  (one GEMM instead of the gamma/beta
+// GEMM + FiLM + mixer Dense),  d n += W_zh d a5  (one GEMM instead of AM^T and AGB^T), and for d v0 the two flipped
+// products  dv = (AM d a5)^T,  1 + gamma = (Wgamma_h^T n)^T + (1 + bgamma):  512 MFMAs per tile instead of 788.
+template <int D, int H, bool BF16, bool STORE, bool ZF>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A) {
+  static_assert(!(ZF && STORE), "the activation store needs the unfolded chain");
   using Cfg = PairCfg<D, BF16>;
   using SM = PairBwdSmem<D, H, BF16>;
   constexpr int KB = Cfg::KB, NT = Cfg::NT, TT = D / 32;
@@ -263,14 +269,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
-  const int bz = blockIdx.x * NW + wave;
+  const int bz = ZF ? (int)blockIdx.x : blockIdx.x * NW + wave;
   const bool active = bz < A.B * A.Z;
   const int bzc = active ? bz : A.B * A.Z - 1;
   const int b = bzc / A.Z;
   const int split = blockIdx.y;
 
   for (int i = tid; i < D; i += NTHREADS) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
-  for (int i = tid; i < 2 * H * D; i += NTHREADS) c_bgb[i] = G(A.L.bgb)[i];
+  if constexpr (ZF) { for (int i = tid; i < H * D; i += NTHREADS) c_bgb[i] = G(A.L.p_opbg)[i]; }     // 1 + bgamma_h
+  else { for (int i = tid; i < 2 * H * D; i += NTHREADS) c_bgb[i] = G(A.L.bgb)[i]; }
   for (int i = tid; i < 2 * D; i += NTHREADS) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
   for (int i = tid; i < SM::GC_BYTES / 4; i += NTHREADS) {
     reinterpret_cast<float*>(gcq)[i] = G(A.L.gcq)[i];
@@ -278,9 +285,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   }
   const int ltstride = enf_lt_stride(H, D);
   const float* ltrow = A.lt + (size_t)bzc * ltstride;
+  if constexpr (ZF) {          // u | c_zh
+    const float* czrow = A.wzb + (size_t)bzc * (H * D);
 #pragma unroll
-  for (int i = lane * 4; i < 2 * H * D; i += 256)
-    *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+    for (int i = lane * 4; i < H * D; i += 256) {
+      *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+      *reinterpret_cast<f32x4*>(zv + H * D + i) = *reinterpret_cast<const f32x4*>(czrow + i);
+    }
+  } else {
+#pragma unroll
+    for (int i = lane * 4; i < 2 * H * D; i += 256)
+      *reinterpret_cast<f32x4*>(zv + i) = *reinterpret_cast<const f32x4*>(ltrow + i);
+  }
   const f32x4 pz = *reinterpret_cast<const f32x4*>(ltrow + enf_lt_off_pose(H, D));
   const float wcoef = ltrow[enf_lt_off_wcoef(H, D)];
   float cz[H];
@@ -293,7 +309,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 
   Pipe P;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
-  P.rs2 = P.rs;
+  constexpr int PANEL_DD = Cfg::DD::BYTES;
+  if constexpr (ZF) P.rs2 = make_blob_rsrc(A.wzt + (size_t)bzc * H * 2 * PANEL_DD, (unsigned)(H * 2 * PANEL_DD));
+  else P.rs2 = P.rs;
+  const unsigned pWG = (unsigned)A.L.awg;
   first_stage<ST_DD>(P, ring, pQ1, wave, lane);
 
   // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature
@@ -303,8 +322,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #if ENF_K3_LDSACC
   float* lacc = reinterpret_cast<float*>(smem + SM::LACC) + wave * (2 * H * NT * 64) + lane;
   // every lane owns its slots: plain read-modify-write (an LDS float atomic costs ~1000 cycles here)
-  auto dU_add = [&](int h, int t, float v) { lacc[(h * NT + t) * 64] += v; };
-  auto dV0_add = [&](int h, int t, float v) { lacc[((H + h) * NT + t) * 64] += v; };
   // flush NT partial sums of one head at once: all reads, then all adds, then all writes (one LDS round trip)
   auto lacc_flush = [&](int slot0, const float (&part)[NT]) {
     float cur[NT];
@@ -337,10 +354,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   }
 
   const int ntiles = (A.N + 15) / 16;
-  const int my_tiles = (ntiles - split + A.nsplit - 1) / A.nsplit;     // tiles split, split+nsplit, ..
+  const int split_tiles = (ntiles - split + A.nsplit - 1) / A.nsplit;  // tiles split, split+nsplit, ..
+  // ZF: the 8 waves share the sweep (wave w takes every 8th tile of the split); all run the same number of steps
+  const int my_tiles = ZF ? (split_tiles + NW - 1) / NW : split_tiles;
   for (int ti = 0; ti < my_tiles; ++ti) {
-    const int n0 = (split + ti * A.nsplit) * 16;
-    const bool nvalid = n0 + col < A.N;
+    const int tk = ZF ? ti * NW + wave : ti;
+    const bool tvalid = tk < split_tiles;
+    const int n0 = tvalid ? (split + tk * A.nsplit) * 16 : 0;
+    const bool nvalid = tvalid && n0 + col < A.N;
     const int n = min(n0 + col, A.N - 1);
     const size_t qrow = (size_t)b * A.N + n;
     const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
@@ -399,7 +420,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         }
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
-      panel_gemm<KB, NT, BF16, ST_GB, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, pGB, true, lane, c_bf);
+      if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, STAGE_RS2, true, lane, c_bf);
+      else panel_gemm<KB, NT, BF16, ST_GB, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, pGB, true, lane, c_bf);
 #if ENF_K3_FUSED_GELU
 #pragma unroll
       for (int t = 0; t < NT; ++t) nh[t] = a3[t];
@@ -428,6 +450,81 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
     for (int t = 0; t < NT; ++t) dnh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (ZF) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const unsigned wzf = STAGE_RS2 | (unsigned)(h * 2 * PANEL_DD), wzb = wzf + PANEL_DD;
+        // ---- a5 = W_zh^T n + c_zh
+        f32x4 a5[NT], v[NT];
+        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a5, F, P, ring, wzf, wzb, true, lane, zv + H * D + h * D);
+        BSTAMP(4 + 6 * h);
+        float mu2, r2;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[t][i] = gelu_f(a5[t][i]);
+        }
+        ln_stats<NT>(v, mu2, r2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[t][i] = (v[t][i] - mu2) * r2;
+        f32x4 dy[NT];
+        {
+          const float* dyrow = A.dybar + qrow * (H * D) + h * D;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t + 4 * quad);
+        }
+        float s0 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s0 = fmaf(dy[t][i], v[t][i], s0);
+        const float datt = xquad_sum(s0);
+        dlogit[h] = nvalid ? att[h] * (datt - A.delta[qrow * H + h]) : 0.f;
+        const float ah = nvalid ? att[h] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { dy[t][i] *= ah; s1 += dy[t][i]; s2 = fmaf(dy[t][i], v[t][i], s2); }
+        const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          K3_OPAQUE(a5[t]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * gelu_grad_f(a5[t][i]);   // d a5
+        }
+        BSTAMP(5 + 6 * h);
+        Frags<BF16, KB> FA;
+        make_frags<BF16, KB>(FA, dy);
+        // ---- d n += W_zh d a5
+        panel_gemm<KB, NT, BF16, ST_DD>(dnh, FA, P, ring, wzb, gM, true, lane);
+        // ---- d v0 += sum_n dv (1 + gamma), both as flipped products (rows = queries)
+        f32x4 dvf[NT];
+        {
+          f32x4 none[1];
+          panel_gemm_flip<KB, NT, BF16, ST_DD, NW, false, INIT_ZERO>(
+              none, FA, P, ring, gM, pWG + h * PANEL_DD, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
+              [&](int mt, const f32x4& af) { dvf[mt] = af; });
+          float part[NT];
+          const unsigned nxt = h + 1 < H ? wzf + 2 * PANEL_DD : gF;
+          panel_gemm_flip<KB, NT, BF16, ST_DD, NW, false>(
+              none, F, P, ring, pWG + h * PANEL_DD, nxt, lane,
+              [&](int mt) { const float bc = c_bgb[h * D + 16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
+              [&](int mt, const f32x4& af) {
+                part[mt] = af[0] * dvf[mt][0] + af[1] * dvf[mt][1] + af[2] * dvf[mt][2] + af[3] * dvf[mt][3];
+              });
+#if ENF_K3_LDSACC
+          lacc_flush((H + h) * NT, part);
+#else
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) dV0_add(h, mt, part[mt]);
+#endif
+        }
+        BSTAMP(6 + 6 * h);
+      }
+    } else
 #pragma unroll
     for (int h = 0; h < H; ++h) {
 #if ENF_K3_PARK
@@ -727,29 +824,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   }
 }
 
-template <int D, int H, bool BF16, bool STORE>
+template <int D, int H, bool BF16, bool STORE, bool ZF>
 static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
   using SM = PairBwdSmem<D, H, BF16>;
-  auto kern = enf_pair_bwd_kernel<D, H, BF16, STORE>;
+  auto kern = enf_pair_bwd_kernel<D, H, BF16, STORE, ZF>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL) != hipSuccess)
       return ENF_ELAUNCH;
     attr_set = true;
   }
-  dim3 grid((A.B * A.Z + NWAVES - 1) / NWAVES, A.nsplit);
+  dim3 grid(ZF ? A.B * A.Z : (A.B * A.Z + NWAVES - 1) / NWAVES, A.nsplit);
   hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SM::TOTAL, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
 extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, const float* lse, const float* dybar, const float* delta, float* dlt,
-                                   void* const* store, hipStream_t st) {
+                                   void* const* store, const char* wzt, const float* wzb, hipStream_t st) {
   PairBwdArgs A;
+  const bool zf = !store && wzt && wzb && (size_t)m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
+  A.wzt = wzt; A.wzb = wzb;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;
   A.dlt = dlt; A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
   // one workgroup per CU is resident (LDS): split the query tiles over grid.y until all 256 CUs have one
-  const int wgs = (m.B * m.Z + NWAVES - 1) / NWAVES, ntiles = (m.N + 15) / 16;
+  const int wgs = zf ? m.B * m.Z : (m.B * m.Z + NWAVES - 1) / NWAVES, ntiles = (m.N + 15) / 16;
   int ns = 1;
   while (wgs * ns < 256 && ns * 2 <= ntiles) ns *= 2;
   A.nsplit = ns;
@@ -757,8 +856,9 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
     for (int i = 0; i < ENF_NUM_STORE(m.H); ++i) A.store[i] = store[i];
 #define ENF_CASE(DD, HH)                                                                   \
   if (m.D == DD && m.H == HH) {                                                            \
-    if (store) return m.bf16 ? launch_pair_bwd<DD, HH, true, true>(A, st) : launch_pair_bwd<DD, HH, false, true>(A, st); \
-    return m.bf16 ? launch_pair_bwd<DD, HH, true, false>(A, st) : launch_pair_bwd<DD, HH, false, false>(A, st);         \
+    if (store) return m.bf16 ? launch_pair_bwd<DD, HH, true, true, false>(A, st) : launch_pair_bwd<DD, HH, false, true, false>(A, st); \
+    if (zf) return m.bf16 ? launch_pair_bwd<DD, HH, true, false, true>(A, st) : launch_pair_bwd<DD, HH, false, false, true>(A, st);    \
+    return m.bf16 ? launch_pair_bwd<DD, HH, true, false, false>(A, st) : launch_pair_bwd<DD, HH, false, false, false>(A, st);         \
   }
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)

@@ -372,7 +372,7 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
-extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, hipStream_t);
+extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
 
 // wz / wzb: scratch for the z-fold variant (enf_workspace: W.wz, W.wzb), or NULL for the latent-split variant
 extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
@@ -390,7 +390,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   if (zfold) {
     A.qg = PairWaves<true>::NW;
     if (run_fold) {
-      int rc = enf_launch_wz(m, L, blob, lt, wz, wzb, wzu, st);
+      int rc = enf_launch_wz(m, L, blob, lt, wz, wzb, wzu, nullptr, st);
       if (rc) return rc;
     }
   }

@@ -22,6 +22,8 @@
 struct WzArgs {
   const float* lt; const char* blob; EnfLayout L;
   char* wz; float* wzb; char* wzu;
+  char* wzt;             // backward-orientation panels (NULL: not wanted)
+  size_t pstride;        // bytes between the panels of consecutive (latent, head) pairs (wz and wzt alike)
   int BZ;
 };
 
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
       }
       make_frags<BF16, KB>(FX[a], X);
     }
-    char* panel = A.wz + (size_t)(bz * H + h) * PB;
+    char* panel = A.wz + (size_t)(bz * H + h) * A.pstride;
     const float* wbmt = G(A.L.p_wbmt) + (size_t)h * D * D;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
@@ -81,7 +83,35 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
           *reinterpret_cast<f32x4*>(panel + (((kt * 2 * KB + 2 * blk + a) * 64 + lane) << 4)) = af[a];
       }
     }
-    if (BF16 && blk == 0 && h == 0) {
+    if (A.wzt) {
+      // the same matrix in backward orientation (A[i][k] = W_zh[i][k], rows = the forward GEMM's INPUT index):
+      // the un-flipped product puts (k-tile, i-columns) tiles in the accumulators, whose lanes hold exactly the
+      // elements of fragment (mt = i-tile, blk = k-block)
+      char* panel_t = A.wzt + (size_t)(bz * H + h) * A.pstride;
+      const float* wbm = G(A.L.p_wbm) + (size_t)h * D * D;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int it = 2 * blk + a;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) acc[kt] = *reinterpret_cast<const f32x4*>(wbm + (size_t)(16 * it + col) * D + 16 * kt + 4 * quad);
+        gemm_stage<BF16, KB, NT>(acc, FX[a], smem, lane);
+        if constexpr (BF16) {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[2 * kb + (j >> 2)][j & 3];
+            *reinterpret_cast<bf16x8*>(panel_t + (((it * KB + kb) * 64 + lane) << 4)) = o;
+          }
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt)
+            *reinterpret_cast<f32x4*>(panel_t + (((it * 2 * KB + kt) * 64 + lane) << 4)) = acc[kt];
+        }
+      }
+    }
+    if (BF16 && A.wzu && blk == 0 && h == 0) {
       // logit vectors as the rows of a bf16 A operand: entry ((kb*4 + kq)*H + hh) = the 8 k-values lane
       // (m = hh, kq) of block kb feeds v_mfma_f32_16x16x32_bf16 (rows m >= H are zero and not stored)
       if (lane < KB * 4 * H) {
@@ -135,9 +165,14 @@ static int launch_wz(const WzArgs& A, hipStream_t st) {
 }
 
 extern "C" int enf_launch_wz(const EnfDims& m, const EnfLayout& L, const char* blob, const float* lt, char* wz, float* wzb,
-                             char* wzu, hipStream_t st) {
+                             char* wzu, char* wzt, hipStream_t st) {
+  // wzt == NULL: forward panels only, packed back to back in wz (the z-fold forward kernel's layout);
+  // wzt != NULL: `wzt` holds [forward | backward] panel pairs per (latent, head) and `wz` is ignored
   WzArgs A;
-  A.lt = lt; A.blob = blob; A.L = L; A.wz = wz; A.wzb = wzb; A.wzu = wzu; A.BZ = m.B * m.Z;
+  const size_t PB = enf_panel_bytes(m.D, m.D, m.bf16);
+  A.lt = lt; A.blob = blob; A.L = L; A.wzb = wzb; A.wzu = wzu; A.BZ = m.B * m.Z;
+  if (wzt) { A.wz = wzt; A.wzt = wzt + PB; A.pstride = 2 * PB; }
+  else { A.wz = wz; A.wzt = nullptr; A.pstride = PB; }
 #define ENF_CASE(DD, HH)                                                                   \
   if (m.D == DD && m.H == HH) return m.bf16 ? launch_wz<DD, HH, true>(A, st) : launch_wz<DD, HH, false>(A, st);
   ENF_CASE(128, 2)

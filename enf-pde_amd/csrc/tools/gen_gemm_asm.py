@@ -102,6 +102,37 @@ def emit_both(KB, MTS, NBUF, mask, name, init="acc"):
 """
 
 
+def emit_flip(KB, MTS, NBUF, init):
+    """Flipped product only (operands swapped: rows = the wave's columns), one accumulator per out-tile."""
+    n = KB * MTS
+    order = [(mt, blk) for blk in range(KB) for mt in range(MTS)]
+    off = lambda mt, blk: (mt * KB + blk) * 1024
+    L = ["s_waitcnt lgkmcnt(0)"]
+    for i in range(min(NBUF, n)):
+        L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i])}")
+    for i, (mt, blk) in enumerate(order):
+        inflight = min(i + NBUF, n) - i
+        L.append(f"s_waitcnt lgkmcnt({inflight - 1})")
+        c = "0" if (init == "zero" and blk == 0) else f"%[a{mt}]"
+        L.append(f"v_mfma_f32_16x16x32_bf16 %[a{mt}], %[b{blk}], %[s{i % NBUF}], {c}")
+        if i + NBUF < n:
+            L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i + NBUF])}")
+    L.append(f"s_nop {TAIL_NOPS}")
+    body = "\n".join(f'      "{x}\\n\\t"' for x in L)
+    outs = ", ".join(_acc_ops(MTS, init) + [f'[s{j}] "=&v"(s{j})' for j in range(NBUF)])
+    ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'])
+    name = {"acc": "run_flip", "zero": "run_flip_zero"}[init]
+    decl = ", ".join(f"s{j}" for j in range(NBUF))
+    return f"""  static __device__ __forceinline__ void {name}(f32x4* acc, const bf16x8* B, unsigned lds_addr) {{
+    f32x4 {decl};
+    asm volatile(
+{body}
+      : {outs}
+      : {ins});
+  }}
+"""
+
+
 BOTH = {(4, 8): [(0xFF, "run_both", 8), (0x33, "run_gb", 8)], (2, 4): [(0xF, "run_both", 6)], (2, 8): [(0x33, "run_gb", 8)]}
 
 
@@ -116,6 +147,8 @@ def main(path):
             out.append("  static constexpr bool available = true;")
             for init in ("acc", "zero", "bias"):
                 out.append(emit(KB, MTS, nb0, init))
+            for init in ("acc", "zero"):
+                out.append(emit_flip(KB, MTS, nb0, init))
             for mask, name, nb in BOTH.get((KB, MTS), []):
                 for init in ("acc", "zero", "bias"):
                     out.append(emit_both(KB, MTS, min(nb, 4) if lite else nb, mask, name, init))

@@ -184,6 +184,7 @@ int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const
  * (DESIGN.md 5).  Also settable with ENF_ZFOLD=0/1 in the environment.  Affects enf_workspace_bytes /
  * enf_pair_scratch_bytes: size buffers after setting it.  Process-wide; meant for tests and benchmarks. */
 void enf_set_zfold(int mode);
+void enf_set_zfold_bwd(int mode);   /* same for the backward pair kernel (ENF_ZFOLD_BWD in the environment) */
 
 #ifdef __cplusplus
 }

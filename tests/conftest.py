@@ -28,3 +28,13 @@ def pair_variant(request):
     lib.enf_set_zfold(1 if request.param == "z_fold" else 0)
     yield request.param
     lib.enf_set_zfold(-1)
+
+
+@pytest.fixture(params=["unfolded", "z_fold"])
+def bwd_variant(request):
+    """Runs a test under both backward pair-kernel variants (enf_set_zfold_bwd, include/enf_hip.h)."""
+    from enf_pde_amd import _lib
+    lib = _lib.load()
+    lib.enf_set_zfold_bwd(1 if request.param == "z_fold" else 0)
+    yield request.param
+    lib.enf_set_zfold_bwd(-1)

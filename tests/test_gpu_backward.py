@@ -8,10 +8,10 @@ from oracle import enf_ref_np as R
 from oracle import enf_ref_torch as T
 from tests.helpers import make_cfg, make_inputs, build_nef
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("bwd_variant")]
 
 # relative L2 error of each gradient tensor
-TOL = {"f32": 2e-4, "bf16": 6e-2}
+TOL = {"f32": 2e-4, "bf16": 7e-2}
 
 
 def ref_grads(prm, cfg, x, p, a, s, w):
