@@ -330,3 +330,39 @@ class EquivariantCrossAttentionNeF:
         return _EnfFunction.apply(x, p, a, sigma, self, packed)
 
     __call__ = apply
+
+    @torch.no_grad()
+    def mse_value_and_latent_grads(self, params, x, p, a, gaussian_window_size, target, grad_scale=1.0):
+        """loss = mean((nef.apply(params, x, p, a, window) - target)^2) and grad_scale * d loss / d(p, a, window) in one
+        sequence of HIP launches (forward, loss + d out, backward), without building an autograd graph: what one
+        inner step of the MAML loop computes (pde_trainer.py:175-207; grad_scale = B there).
+        Returns (loss (1,), dp, da, dwindow or None)."""
+        lib = _lib.load()
+        sigma = gaussian_window_size if self.use_gaussian_window else None
+        packed = self.pack(params)
+        x, p_, a_ = x.float(), p.float().contiguous(), a.float().contiguous()
+        s_ = sigma.float().reshape(p_.shape[0], p_.shape[1], 1).contiguous() if sigma is not None else None
+        B, Z, N, dev = p_.shape[0], p_.shape[1], x.shape[1], p_.device
+        desc = self._desc(B, N, Z)
+        xb, xstride = self._x_arg(x)
+        HD = self.num_heads * self.num_hidden
+        out = torch.empty((B, N, self.num_out), device=dev, dtype=torch.float32)
+        ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
+        lse = torch.empty((B, N, self.num_heads), device=dev, dtype=torch.float32)
+        ws = self._workspace(desc, dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.enf_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
+                                   _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), st))
+        tgt = target.float().contiguous()
+        if tgt.shape != out.shape:
+            raise AssertionError(f"target has shape {tuple(tgt.shape)}, expected {tuple(out.shape)}")
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        dout = torch.empty_like(out)
+        _lib.check(lib.enf_mse_value_grad(_ptr(out), _ptr(tgt), out.numel(), float(grad_scale), _ptr(dout), _ptr(loss), st))
+        dp, da = torch.empty_like(p_), torch.empty_like(a_)
+        dsig = torch.empty((B, Z, 1), device=dev, dtype=torch.float32)
+        _lib.check(lib.enf_backward_latents_ex(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_),
+                                               _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
+                                               _ptr(dsig), _ptr(ws), ws.numel(), 1, st))       # the latent table is the forward's
+        self._ws_touch(ws)
+        return loss, dp, da, (dsig if sigma is not None else None)

@@ -29,8 +29,9 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
     latents0 : {'p_pos','a','gaussian_window'[,'p_ori']} with leading dim 1 (the meta-init)
     lrs      : inner learning rates, same keys
     coords   : (N, dx) grid;  img: (B, N, O) targets;  masks: (N_s, S+1) long
-    Each step is one HIP forward + one HIP backward-to-latents; the gradient of the batch-mean
-    loss is multiplied by B (pde_trainer.py:207) so signals are independent.
+    Each step is one HIP forward, the fused loss/d-out kernel and one HIP backward-to-latents
+    (nef.mse_value_and_latent_grads: no autograd graph); the gradient of the batch-mean loss is multiplied by B
+    (pde_trainer.py:207) so signals are independent.
     Returns (loss on the last mask, fitted latents dict with leading dim B).
     """
     B = img.shape[0]
@@ -41,26 +42,28 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
         lat["p_pos"] = lat["p_pos"] + torch.randn(lat["p_pos"].shape, generator=generator,
                                                   device="cpu").to(lat["p_pos"].device) * noise_pos
 
-    def loss_fn(lat, s):
-        xs = coords[masks[:, s]][None].expand(B, -1, -1)                # stride-0 batch (pde_trainer.py:193-197)
-        ys = img[:, masks[:, s]]
-        out = nef.apply(nef_params, xs, _pose(lat, n_ori), lat["a"], lat["gaussian_window"])
-        return ((out - ys) ** 2).mean()                                 # pde_trainer.py:185
-
+    # coordinates and targets of all S+1 steps gathered once                 (pde_trainer.py:193-197)
+    xs_all = coords[masks.t()]                                           # (S+1, N_s, dx)
+    ys_all = img[:, masks.t()].transpose(0, 1).contiguous()              # (S+1, B, N_s, O)
+    n_pos = lat["p_pos"].shape[-1]
+    # update coefficients -lr * B (pde_trainer.py:207,215-219); sigma only moves when asked to (pde_trainer.py:210-212)
+    coef = {k: -(lrs[k] * B) for k in lat}
     for s in range(S):                                                  # pde_trainer.py:191
-        leaves = {k: v.detach().requires_grad_(True) for k, v in lat.items()}
-        keys = [k for k in leaves if not (k == "gaussian_window" and not nef.use_gaussian_window)]
-        grads = torch.autograd.grad(loss_fn(leaves, s), [leaves[k] for k in keys], allow_unused=True)
-        new = {}
-        for k in leaves:
-            g = dict(zip(keys, grads)).get(k)
-            g = torch.zeros_like(leaves[k]) if g is None else g * B                            # pde_trainer.py:207
-            if k == "gaussian_window" and not optimize_gaussian_window:                        # pde_trainer.py:210-212
-                g = torch.zeros_like(g)
-            new[k] = (leaves[k] - lrs[k] * g).detach()                                         # pde_trainer.py:215-219
+        xs = xs_all[s][None].expand(B, -1, -1)                          # stride-0 batch
+        _, dp, da, dsig = nef.mse_value_and_latent_grads(nef_params, xs, _pose(lat, n_ori), lat["a"],
+                                                         lat.get("gaussian_window"), ys_all[s])
+        new = dict(lat)
+        new["p_pos"] = torch.addcmul(lat["p_pos"], dp[..., :n_pos], coef["p_pos"])
+        if n_ori > 0:
+            new["p_ori"] = torch.addcmul(lat["p_ori"], dp[..., n_pos:], coef["p_ori"])
+        new["a"] = torch.addcmul(lat["a"], da, coef["a"])
+        if optimize_gaussian_window and dsig is not None:
+            new["gaussian_window"] = torch.addcmul(lat["gaussian_window"], dsig, coef["gaussian_window"])
         lat = new
-    with torch.no_grad():
-        loss = loss_fn(lat, S)                                          # pde_trainer.py:225-235
+    with torch.no_grad():                                               # pde_trainer.py:225-235
+        xs = xs_all[S][None].expand(B, -1, -1)
+        out = nef.apply(nef_params, xs, _pose(lat, n_ori), lat["a"], lat.get("gaussian_window"))
+        loss = ((out - ys_all[S]) ** 2).mean()
     return loss, lat
 
 

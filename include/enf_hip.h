@@ -180,6 +180,11 @@ int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const
                       const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
                       void* stream);
 
+/* Reconstruction loss of the inner loop and its gradient in one pass (pde_trainer.py:185):
+ *   *loss += mean((out - target)^2)   (the caller zeroes *loss),   dout = 2 (out - target) / n * grad_scale  (dout may be NULL) */
+int enf_mse_value_grad(const float* out, const float* target, size_t n, float grad_scale, float* dout, float* loss,
+                       void* stream);
+
 /* Forward pair-kernel variant: -1 = choose by problem size (default), 0 = latent-split, 1 = z-fold
  * (DESIGN.md 5).  Also settable with ENF_ZFOLD=0/1 in the environment.  Affects enf_workspace_bytes /
  * enf_pair_scratch_bytes: size buffers after setting it.  Process-wide; meant for tests and benchmarks. */
