@@ -122,3 +122,53 @@ def test_nef_train_step_follows_optax_rules(cuda):
         l, st = tr.nef_train_step(st, batch, masks=mk)
         losses.append(float(l))
     assert losses[-1] < losses[0], losses
+
+
+def test_nonmeta_train_step(cuda):
+    """Auto-decoder trainer (nonmaml_pde_trainer.py:101-137): first-order loss gradient w.r.t. weights and the selected
+    latent rows against fp64 autograd of the oracle, then the optax-rule updates."""
+    from enf_pde_amd.fitting.trainers import NonMetaPDETrainer
+    from enf_pde_amd.enf.latents.autodecoder import PositionOrientationFeatureAutodecoder
+    cfg, prm, coords, img, _, _, _ = _problem(seed=5, B=3, Z=9)
+    nef = build_nef(cfg, "f32")
+    conf = NS(optimizer=NS(learning_rate_enf=1e-3, learning_rate_codes=1e-2), training=NS(max_num_sampled_points=10 ** 6))
+    ad = PositionOrientationFeatureAutodecoder(6, 9, 8, 2, 0, gaussian_window_size=-1)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    tr = NonMetaPDETrainer(conf, nef, ad, t(coords), seed=0)
+    state = tr.init_train_state(nef.load_params(prm, device=cuda))
+    P0 = {k: v.clone() for k, v in state.params["autodecoder"]["params"].items()}
+    P0["a"] = P0["a"] + 0.1 * torch.randn(P0["a"].shape, generator=torch.Generator().manual_seed(1)).to(cuda)
+    state.params["autodecoder"]["params"] = {k: v.clone() for k, v in P0.items()}
+    idx = torch.tensor([4, 0, 2], device=cuda)
+    batch = (t(img).reshape(3, 8, 8, 1), idx)
+    loss, gw, ga = tr.loss_and_grads(state, batch[0], idx)
+    # oracle
+    tp = T.to_torch(prm, torch.float64, requires_grad=True)
+    lat = {k: torch.tensor(v.cpu().numpy().astype(np.float64), requires_grad=True) for k, v in P0.items()}
+    out = T.nef_apply(tp, cfg, torch.tensor(coords)[None].expand(3, -1, -1), lat["p_pos"][idx.cpu()], lat["a"][idx.cpu()],
+                      lat["gaussian_window"][idx.cpu()])
+    lref = ((out - torch.tensor(img)) ** 2).mean()
+    leaves = [_get(tp["params"], p) for p in TENSOR_PATHS]
+    g = torch.autograd.grad(lref, leaves + [lat[k] for k in ("p_pos", "a")], allow_unused=True)
+    lref = lref.detach()
+    assert abs(float(loss) - float(lref)) < 1e-5 * max(1.0, float(lref))
+    gmax = max(float(x.norm()) for x in g[:len(leaves)] if x is not None)
+    for path, a, b in zip(TENSOR_PATHS, gw, g[:len(leaves)]):
+        if b is None:
+            assert float(a.abs().max()) == 0
+            continue
+        nb = float(b.norm())
+        e = float((a.cpu().double() - b).norm()) / (nb if nb > 1e-3 * gmax else gmax)
+        assert e < 1e-3, ("/".join(path), e)
+    for k, b in zip(("p_pos", "a"), g[len(leaves):]):
+        e = float((ga[k].cpu().double() - b).norm() / b.norm())
+        assert e < 1e-3, (k, e)
+        assert float(ga[k][[1, 3, 5]].abs().max()) == 0          # rows outside the batch get no gradient
+    loss2, new = tr.nef_train_step(state, batch)
+    ref_a, _ = O.adam_step([P0["a"].cpu().numpy().astype(np.float64)], [ga["a"].cpu().numpy().astype(np.float64)],
+                           O.init_state([P0["a"].cpu().numpy()]), lr=1e-2)
+    np.testing.assert_allclose(new.params["autodecoder"]["params"]["a"].cpu().numpy(), ref_a[0], rtol=2e-4, atol=2e-6)
+    l0 = float(loss2)
+    for _ in range(10):
+        l, new = tr.nef_train_step(new, batch)
+    assert float(l) < l0
