@@ -184,3 +184,27 @@ def test_get_model_pde_and_fit_helpers():
         parts = [shard_range(n, r, w) for r in range(w)]
         assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """flat .npz of the Flax-named tree: save_tree / load_tree round-trip, and the 46 tensor paths survive."""
+    import numpy as np
+    import torch
+    from oracle import enf_ref_np as R
+    from tests.helpers import make_cfg
+    from enf_pde_amd.checkpoint import save_tree, load_tree, flatten_tree
+    from enf_pde_amd.enf.models import TENSOR_PATHS
+    cfg = make_cfg("ponita", D=64, H=2, C=8, O=2)
+    prm = R.init_params(0, cfg, jitter=0.1)
+    path = tmp_path / "nef.npz"
+    save_tree(path, prm)
+    back = load_tree(path)
+    flat_a, flat_b = flatten_tree(prm), flatten_tree(back)
+    assert set(flat_a) == set(flat_b) and len(flat_a) == len(TENSOR_PATHS)
+    for k in flat_a:
+        np.testing.assert_allclose(np.asarray(flat_a[k], dtype=np.float32), flat_b[k].numpy(), rtol=0, atol=0)
+    for p in TENSOR_PATHS:
+        assert "params/" + "/".join(p) in flat_b
+    lat = {"params": {"p_pos": torch.zeros(2, 4, 2), "a": torch.ones(2, 4, 8), "gaussian_window": torch.full((2, 4, 1), 0.5)}}
+    save_tree(tmp_path / "lat.npz", lat)
+    assert torch.equal(load_tree(tmp_path / "lat.npz")["params"]["a"], lat["params"]["a"])
