@@ -38,19 +38,36 @@ def lt_layout(desc):
     return dict(zip(("stride", "u", "v0", "pose", "wcoef", "c"), [t.value for t in v]))
 
 
+SPLIT_K = 4096      # rows per slice of the pair axis: a (D x P)(P x D) product has only D^2/tile^2 output tiles, so the
+                    # library GEMM is run batched over slices of P (split-K) and the slices are summed in fp32
+
+
 def _xt_dot(X, Dl):
-    """X^T @ Dl with fp32 accumulation and fp32 result (X, Dl: (P, D) bf16 or fp32)."""
-    if X.dtype == torch.float32:
-        return X.t() @ Dl
-    try:
-        return torch.mm(X.t(), Dl, out_dtype=torch.float32)
-    except (TypeError, RuntimeError, NotImplementedError):
-        acc = None
-        step = 1 << 16
-        for i in range(0, X.shape[0], step):
-            part = (X[i:i + step].t() @ Dl[i:i + step]).float()
-            acc = part if acc is None else acc + part
-        return acc
+    """X^T @ Dl with fp32 accumulation and fp32 result (X, Dl: (P, D) bf16 or fp32), parallel over the pair axis."""
+    P, D = X.shape
+    nfull = P // SPLIT_K
+    out = None
+    if nfull:
+        Xb = X[:nfull * SPLIT_K].view(nfull, SPLIT_K, D).transpose(1, 2)
+        Db = Dl[:nfull * SPLIT_K].view(nfull, SPLIT_K, D)
+        if X.dtype == torch.float32:
+            out = torch.bmm(Xb, Db).sum(0)
+        else:
+            try:
+                out = torch.bmm(Xb, Db, out_dtype=torch.float32).sum(0)
+            except (TypeError, RuntimeError, NotImplementedError):
+                out = torch.bmm(Xb, Db).float().sum(0)
+    if nfull * SPLIT_K < P:
+        xr, dr = X[nfull * SPLIT_K:], Dl[nfull * SPLIT_K:]
+        if X.dtype == torch.float32:
+            rem = xr.t() @ dr
+        else:
+            try:
+                rem = torch.mm(xr.t(), dr, out_dtype=torch.float32)
+            except (TypeError, RuntimeError, NotImplementedError):
+                rem = (xr.t() @ dr).float()
+        out = rem if out is None else out + rem
+    return out
 
 
 class _PairFunction(torch.autograd.Function):
