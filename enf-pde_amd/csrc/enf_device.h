@@ -367,6 +367,12 @@ DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, ch
     if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     if (active) gemm_stage<BF16, KBIN, C::MTS, INIT>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane, bias + 16 * sp * C::MTS);
+    else if constexpr (INIT != INIT_ACC) {        // a wave that only keeps the barrier cadence still gets defined values
+#pragma unroll
+      for (int mt = 0; mt < C::MTS; ++mt)
+        acc[sp * C::MTS + mt] = INIT == INIT_BIAS ? *reinterpret_cast<const f32x4*>(bias + 16 * (sp * C::MTS + mt) + 4 * (lane >> 4))
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     stage_close(P);
   }
 }

@@ -47,6 +47,10 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #define STAMP(k) do {} while (0)
 #endif
 
+#ifndef ENF_K2_BIAS_IN_STAGE
+#define ENF_K2_BIAS_IN_STAGE 0   // measured: 1.19 vs 1.135 ms with the bias loads inside the asm stage (K2 has registers to spare)
+#endif
+#define K2_INIT (ENF_K2_BIAS_IN_STAGE ? INIT_BIAS : INIT_ACC)
 #ifndef ENF_ZFOLD_WAVES
 #define ENF_ZFOLD_WAVES 8
 #endif
@@ -170,10 +174,8 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acq, lane, quad);
       make_frags<BF16, KB>(F, acc);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bq1, t, quad);
       STAMP(1);
-      panel_gemm<KB, NT, BF16, ST_DD, NW>(acc, F, P, ring, pQ1, pV1, active, lane);
+      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pQ1, pV1, active, lane, c_bq1);
       STAMP(2);
       if constexpr (ZFOLD && BF16) {
         // logits on the matrix pipe: rows 0..H-1 of the A operand are u_zh (bf16, packed by enf_wz_kernel),
@@ -208,18 +210,14 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
       make_frags<BF16, KB>(F, acc);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bv1, t, quad);
       STAMP(4);
-      panel_gemm<KB, NT, BF16, ST_DD, NW>(acc, F, P, ring, pV1, pF, active, lane);
+      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pV1, pF, active, lane, c_bv1);
       STAMP(5);
       make_frags<BF16, KB>(F, acc);
       relu_frags<BF16, KB>(F);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = rowvec(c_bf, t, quad);
       STAMP(6);
-      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(ENF_ABL_SAMEPANEL ? 0 : z * H * PANEL_DD), active, lane);
-      else panel_gemm<KB, NT, BF16, ST_GB, NW>(acc, F, P, ring, pF, pGB, active, lane);
+      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(ENF_ABL_SAMEPANEL ? 0 : z * H * PANEL_DD), active, lane, c_bf);
+      else panel_gemm<KB, NT, BF16, ST_GB, NW, K2_INIT>(acc, F, P, ring, pF, pGB, active, lane, c_bf);
       STAMP(7);
       gelu_tiles<NT, BF16>(acc);
       float mu, rstd;
@@ -237,11 +235,9 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       f32x4 v[NT];
       if constexpr (ZFOLD) {
         const unsigned wzh = STAGE_RS2 | (unsigned)(((ENF_ABL_SAMEPANEL ? 0 : z) * H + h) * PANEL_DD);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) v[t] = rowvec(zv + H * D + h * D, t, quad);
         STAMP(10 + 4 * h);
-        panel_gemm<KB, NT, BF16, ST_DD, NW>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
-                                        active, lane);
+        panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
+                                                 active, lane, zv + H * D + h * D);
       } else {
         f32x4 dummy[1];
         gb_panel<D, BF16, ST_DD, false, NW>(v, dummy, F, P, ring, pGB + h * PANEL_GB, pM, active, c_bgb + 2 * h * D,
@@ -249,11 +245,9 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
         STAMP(9 + 4 * h);
         Frags<BF16, KB> FV;
         make_frags<BF16, KB>(FV, v);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) v[t] = rowvec(c_bm, t, quad);
         STAMP(10 + 4 * h);
-        if (h + 1 < H) panel_gemm<KB, NT, BF16, ST_GB, NW>(v, FV, P, ring, pM, pGB + (h + 1) * PANEL_GB, active, lane);
-        else panel_gemm<KB, NT, BF16, ST_DD, NW>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane);
+        if (h + 1 < H) panel_gemm<KB, NT, BF16, ST_GB, NW, K2_INIT>(v, FV, P, ring, pM, pGB + (h + 1) * PANEL_GB, active, lane, c_bm);
+        else panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane, c_bm);
       }
       STAMP(11 + 4 * h);
       gelu_tiles<NT, BF16>(v);
