@@ -51,6 +51,13 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #define ENF_K2_BIAS_IN_STAGE 0   // measured: 1.19 vs 1.135 ms with the bias loads inside the asm stage (K2 has registers to spare)
 #endif
 #define K2_INIT (ENF_K2_BIAS_IN_STAGE ? INIT_BIAS : INIT_ACC)
+// accumulators start from the bias row vector: loaded here (INIT_ACC) or inside the asm stage (INIT_BIAS)
+#define K2_BIAS(ACC, PTR)                                                              \
+  do {                                                                                 \
+    if (K2_INIT == INIT_ACC) {                                                         \
+      _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) ACC[t_] = rowvec(PTR, t_, quad); \
+    }                                                                                  \
+  } while (0)
 #ifndef ENF_ZFOLD_WAVES
 #define ENF_ZFOLD_WAVES 8
 #endif
@@ -174,6 +181,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acq, lane, quad);
       make_frags<BF16, KB>(F, acc);
+      K2_BIAS(acc, c_bq1);
       STAMP(1);
       panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pQ1, pV1, active, lane, c_bq1);
       STAMP(2);
@@ -210,11 +218,13 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
       make_frags<BF16, KB>(F, acc);
+      K2_BIAS(acc, c_bv1);
       STAMP(4);
       panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pV1, pF, active, lane, c_bv1);
       STAMP(5);
       make_frags<BF16, KB>(F, acc);
       relu_frags<BF16, KB>(F);
+      K2_BIAS(acc, c_bf);
       STAMP(6);
       if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(ENF_ABL_SAMEPANEL ? 0 : z * H * PANEL_DD), active, lane, c_bf);
       else panel_gemm<KB, NT, BF16, ST_GB, NW, K2_INIT>(acc, F, P, ring, pF, pGB, active, lane, c_bf);
@@ -235,6 +245,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       f32x4 v[NT];
       if constexpr (ZFOLD) {
         const unsigned wzh = STAGE_RS2 | (unsigned)(((ENF_ABL_SAMEPANEL ? 0 : z) * H + h) * PANEL_DD);
+        K2_BIAS(v, zv + H * D + h * D);
         STAMP(10 + 4 * h);
         panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
                                                  active, lane, zv + H * D + h * D);
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
         STAMP(9 + 4 * h);
         Frags<BF16, KB> FV;
         make_frags<BF16, KB>(FV, v);
+        K2_BIAS(v, c_bm);
         STAMP(10 + 4 * h);
         if (h + 1 < H) panel_gemm<KB, NT, BF16, ST_GB, NW, K2_INIT>(v, FV, P, ring, pM, pGB + (h + 1) * PANEL_GB, active, lane, c_bm);
         else panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(v, FV, P, ring, pM, it + 1 < iters ? pQ1 : NO_STAGE, active, lane, c_bm);
