@@ -1,6 +1,7 @@
 // enf_api.hip -- the C-ABI of include/enf_hip.h: validation, workspace carving, kernel sequencing.
 // No allocation, no host synchronisation, no global state besides one-time kernel attributes.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "enf_layout.h"
 
 extern "C" {
@@ -100,6 +101,29 @@ extern "C" int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, 
                             ENF_STAGE_PROLOGUE | ENF_STAGE_FOLD | ENF_STAGE_PAIR | ENF_STAGE_TAIL, stream);
 }
 
+// One side stream per process for work that can overlap the caller's stream (created on first use; ENF_SIDE_STREAM=0
+// disables it).  Fork / join is by events, so the caller's stream order is preserved; the mutex keeps concurrent host
+// threads from interleaving their record / wait pairs on the shared events.
+struct SideStream { hipStream_t s; hipEvent_t fork, join; std::mutex mu; };
+static SideStream* side_stream() {
+  static SideStream* S = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* e = getenv("ENF_SIDE_STREAM");
+    if (!(e && e[0] == '0')) {
+      SideStream* t = new SideStream();
+      if (hipStreamCreateWithFlags(&t->s, hipStreamNonBlocking) == hipSuccess &&
+          hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&t->join, hipEventDisableTiming) == hipSuccess)
+        S = t;
+      else
+        delete t;
+    }
+  }
+  return S;
+}
+
 extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
                                     const float* sigma, const void* packed, const float* ybar, const float* lse,
                                     const float* dout, float* dp, float* da, float* dsigma, void* workspace,
@@ -128,10 +152,24 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
   // caller vouches that nothing has touched the workspace since the matching enf_forward
   if (!(flags & ENF_BWD_REUSE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st)))
     return rc;
+  // z-fold backward: the per-latent matrices depend on the latent table only, so enf_wz_kernel runs on a side stream
+  // (fork / join by events) beside the tail backward instead of in front of the pair kernel
+  const bool zb = enf_use_zfold_bwd(m);
+  SideStream* side = zb ? side_stream() : nullptr;
+  if (zb) {
+    if (side) {
+      std::lock_guard<std::mutex> lk(side->mu);
+      if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
+      if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, side->s))) return rc;
+      if (hipEventRecord(side->join, side->s) != hipSuccess) return ENF_ELAUNCH;
+    } else if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, st))) return rc;
+  }
   if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, st))) return rc;
   if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
-  const bool zb = enf_use_zfold_bwd(m);
-  if (zb && (rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, st))) return rc;
+  if (zb && side) {
+    std::lock_guard<std::mutex> lk(side->mu);
+    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ENF_ELAUNCH;
+  }
   if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr,
                                 zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, st))) return rc;
   if ((rc = enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st))) return rc;

@@ -64,23 +64,34 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
     }
     char* panel = A.wz + (size_t)(bz * H + h) * A.pstride;
     const float* wbmt = G(A.L.p_wbmt) + (size_t)h * D * D;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      f32x4 af[2];
+    {
+      // forward orientation: flipped product of all NT k-tiles for the two i-tiles of this block (hand-scheduled
+      // stage when available), then lane-linear fragment stores
+      f32x4 af[2][NT];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        af[a] = *reinterpret_cast<const f32x4*>(wbmt + (size_t)(16 * kt + col) * D + 16 * (2 * blk + a) + 4 * quad);
-        gemm_tile_flip<BF16, KB>(af[a], FX[a], smem, kt, lane);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+          af[a][kt] = *reinterpret_cast<const f32x4*>(wbmt + (size_t)(16 * kt + col) * D + 16 * (2 * blk + a) + 4 * quad);
+        if constexpr (BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, NT>::available) {
+          GemmStageAsm<KB, NT>::run_flip(af[a], FX[a].f, (unsigned)(uintptr_t)(lds_ptr_t)(smem + (lane << 4)));
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) gemm_tile_flip<BF16, KB>(af[a][kt], FX[a], smem, kt, lane);
+        }
       }
-      if constexpr (BF16) {
-        bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)af[j >> 2][j & 3];
-        *reinterpret_cast<bf16x8*>(panel + (((kt * KB + blk) * 64 + lane) << 4)) = o;
-      } else {
+      for (int kt = 0; kt < NT; ++kt) {
+        if constexpr (BF16) {
+          bf16x8 o;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-          *reinterpret_cast<f32x4*>(panel + (((kt * 2 * KB + 2 * blk + a) * 64 + lane) << 4)) = af[a];
+          for (int j = 0; j < 8; ++j) o[j] = (__bf16)af[j >> 2][kt][j & 3];
+          *reinterpret_cast<bf16x8*>(panel + (((kt * KB + blk) * 64 + lane) << 4)) = o;
+        } else {
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            *reinterpret_cast<f32x4*>(panel + (((kt * 2 * KB + 2 * blk + a) * 64 + lane) << 4)) = af[a][kt];
+        }
       }
     }
     if (A.wzt) {
