@@ -28,6 +28,9 @@ struct WzArgs {
 };
 
 constexpr int WZ_WAVES = 4;
+#ifndef ENF_WZ_MAXGRID
+#define ENF_WZ_MAXGRID 1024
+#endif
 
 template <int D, int H, bool BF16>
 __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
@@ -170,7 +173,7 @@ static int launch_wz(const WzArgs& A, hipStream_t st) {
   }
   const int ntask = A.BZ * H * (D / 32);
   int grid = (ntask + WZ_WAVES - 1) / WZ_WAVES;
-  if (grid > 1024) grid = 1024;
+  if (grid > ENF_WZ_MAXGRID) grid = ENF_WZ_MAXGRID;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WZ_WAVES), PB, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
