@@ -81,6 +81,26 @@ def one_step(nef, params, lat0, lrs, coords, img, masks):
     return loss, recon
 
 
+def split_leg(nef, params, lat0, lrs, coords, img, masks, device, iters=10):
+    """the fit and the decode halves of a step timed separately (rank 0, outside the timed region):
+    qps_fit = B (S+1) N_s / t_fit, qps_decode = B N / t_decode."""
+    from enf_pde_amd.fitting import inner_loop, decode
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    _, lat = inner_loop(nef, params, lat0, lrs, coords, img, masks)
+    torch.cuda.synchronize(device)
+    ev[0].record()
+    for _ in range(iters):
+        _, lat = inner_loop(nef, params, lat0, lrs, coords, img, masks)
+    ev[1].record()
+    for _ in range(iters):
+        decode(nef, params, coords, lat["p_pos"], lat["a"], lat["gaussian_window"])
+    ev[2].record()
+    torch.cuda.synchronize(device)
+    t_fit, t_dec = ev[0].elapsed_time(ev[1]) / iters * 1e-3, ev[1].elapsed_time(ev[2]) / iters * 1e-3
+    return {"qps_fit": round(B_PER_GPU * (S + 1) * N_S / t_fit, 1), "qps_decode": round(B_PER_GPU * N / t_dec, 1),
+            "ms_fit": round(t_fit * 1e3, 4), "ms_decode": round(t_dec * 1e3, 4), "n_gpus": 1}
+
+
 def roofline_leg(nef, params, coords, device, iters=20):
     """Time enf_pair_fwd_kernel alone (decode shape) with events on the launch stream."""
     from enf_pde_amd import _lib
@@ -218,6 +238,7 @@ def main():
         "final_fit_loss": round(float(loss), 6),
     }
     if rank == 0:
+        result["split"] = split_leg(nef, params, lat0, lrs, coords, img, masks, device)
         result["roofline"] = roofline_leg(nef, params, coords, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg()

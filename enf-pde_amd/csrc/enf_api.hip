@@ -51,6 +51,7 @@ extern "C" int enf_check_desc(const EnfDesc* d) {
                      d->invariant_id == ENF_INV_LATITUDE_PERIODIC || d->invariant_id == ENF_INV_POLAR_PERIODIC;
   if (two_d && d->dx != 2) return ENF_EDIM;     // reference: assert cfg.num_in == 2 (invariant/__init__.py:62,65)
   if (!(d->D == 64 || d->D == 128)) return ENF_EUNSUPPORTED;
+  if (d->d_true < 0 || d->d_true > d->D || (d->d_true & 1)) return ENF_EINVAL;
   if (!(d->H == 1 || d->H == 2)) return ENF_EUNSUPPORTED;
   if (d->O > 32) return ENF_EUNSUPPORTED;
   if (d->precision != ENF_PREC_F32 && d->precision != ENF_PREC_BF16) return ENF_EINVAL;

@@ -441,14 +441,14 @@ DEV void first_stage(Pipe& P, char* ring, unsigned panel, int wave, int lane) {
 
 // LayerNorm statistics over the NT*16 features of this lane's column: biased variance, eps 1e-6,
 // one pass (E[x^2] - E[x]^2, flax.linen.LayerNorm's default use_fast_variance=True)
-template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd) {
+template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd, float inv_n = 1.0f / (16 * NT)) {
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += X[t][i]; q = fmaf(X[t][i], X[t][i], q); }
-  mu = xquad_sum(s) * (1.0f / (16 * NT));
-  const float ex2 = xquad_sum(q) * (1.0f / (16 * NT));
+  mu = xquad_sum(s) * inv_n;          // inv_n = 1 / (number of real features): zero padding adds nothing to the sums
+  const float ex2 = xquad_sum(q) * inv_n;
   rstd = rsqrtf(fmaxf(ex2 - mu * mu, 0.f) + 1e-6f);
 }
 

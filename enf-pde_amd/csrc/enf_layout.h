@@ -27,6 +27,7 @@
 
 struct EnfDims {
   int B, N, Z, H, D, C, O, dx, dp, I, inv, use_window, bf16;
+  int Dt;      // the model's true num_hidden (== D unless zero-padded): LayerNorm divisors, logit scale
   int HD;      // H*D
   int KB;      // D/32   in/out blocks of a D-wide activation
   int KBH;     // HD/32
@@ -63,6 +64,7 @@ inline EnfDims enf_dims(const EnfDesc* d) {
   m.B = d->B; m.N = d->N; m.Z = d->Z; m.H = d->H; m.D = d->D; m.C = d->C; m.O = d->O;
   m.dx = d->dx; m.inv = d->invariant_id; m.use_window = d->use_window;
   m.bf16 = d->precision == ENF_PREC_BF16;
+  m.Dt = d->d_true > 0 ? d->d_true : d->D;
   m.I = enf_inv_dim(m.inv, m.dx); m.dp = enf_inv_pose_dim(m.inv, m.dx);
   m.HD = m.H * m.D; m.KB = m.D / 32; m.KBH = m.HD / 32; m.OB = (m.O + 31) / 32;
   return m;

@@ -224,7 +224,7 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
   auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
   const int D = m.D, H = m.H, HD = m.HD, C = m.C, O = m.O, OP = 32 * m.OB;
   const size_t f = sizeof(float);
-  const float scale = 1.0f / sqrtf((float)D);  // ECA:59
+  const float scale = 1.0f / sqrtf((float)m.Dt);  // ECA:59 (num_hidden, not a padded width)
   auto cp = [&](size_t off, const float* src, size_t n) {
     return hipMemcpyAsync(blob + off, src, n * f, hipMemcpyDeviceToDevice, st);
   };
@@ -305,6 +305,7 @@ struct PrologueArgs {
   const char* blob; EnfLayout L;
   float* lt; float* an; float* kv;
   int BZ, H, D, C, dp, inv;
+  int Dt;                // true num_hidden (LayerNorm statistics); D may be a zero-padded width
 };
 
 __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
@@ -346,11 +347,11 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
   for (int zz = wave; zz < ZT; zz += 4) {
     const int r = row0 + zz;
     float v = 0.f;
-    for (int d = lane; d < D; d += 64) v += s_an[d * ZT + zz];
-    const float mu = wave_sum(v) / D;
+    for (int d = lane; d < A.Dt; d += 64) v += s_an[d * ZT + zz];          // statistics over the real features only
+    const float mu = wave_sum(v) / A.Dt;
     float q = 0.f;
-    for (int d = lane; d < D; d += 64) { const float t = s_an[d * ZT + zz] - mu; q += t * t; }
-    const float rstd = rsqrtf(wave_sum(q) / D + 1e-6f);
+    for (int d = lane; d < A.Dt; d += 64) { const float t = s_an[d * ZT + zz] - mu; q += t * t; }
+    const float rstd = rsqrtf(wave_sum(q) / A.Dt + 1e-6f);
     for (int d = lane; d < D; d += 64) {
       const float sv = s_an[d * ZT + zz];
       const float xn = (sv - mu) * rstd;
@@ -450,7 +451,7 @@ extern "C" int enf_launch_prologue(const EnfDims& m, const EnfLayout& L, const c
                                    const float* sigma, float* lt, float* an, float* kv, hipStream_t st) {
   PrologueArgs A;
   A.p = p; A.a = a; A.sigma = sigma; A.blob = blob; A.L = L; A.lt = lt; A.an = an; A.kv = kv;
-  A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp = m.dp; A.inv = m.inv;
+  A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp = m.dp; A.inv = m.inv; A.Dt = m.Dt;
   const size_t smem = sizeof(float) * (ZT * m.C + ZT * m.D + ZT * m.HD);
   hipLaunchKernelGGL(enf_prologue_kernel, dim3((A.BZ + ZT - 1) / ZT), dim3(256), smem, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
@@ -465,6 +466,7 @@ struct PrologueBwdArgs {
   const float* an; const float* kv; const float* dlt;
   float* dp; float* da; float* dsigma;
   int BZ, H, D, C, dp_dim, inv;
+  int Dt;
 };
 
 __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A) {
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
     const float* anr = A.an + (size_t)rr * (2 * D + 2);
     float v1 = 0.f, v2 = 0.f;
     for (int d = lane; d < D; d += 64) { const float g = s_dan[d * ZT + zz]; v1 += g; v2 += g * anr[D + d]; }
-    const float m1 = wave_sum(v1) / D, m2 = wave_sum(v2) / D;
+    const float m1 = wave_sum(v1) / A.Dt, m2 = wave_sum(v2) / A.Dt;
     const float rstd = anr[2 * D + 1];
     for (int d = lane; d < D; d += 64) s_dan[d * ZT + zz] = rstd * (s_dan[d * ZT + zz] - m1 - anr[D + d] * m2);
   }
@@ -576,7 +578,7 @@ extern "C" int enf_launch_prologue_bwd(const EnfDims& m, const EnfLayout& L, con
   PrologueBwdArgs A;
   A.p = p; A.sigma = sigma; A.blob = blob; A.L = L; A.an = an; A.kv = kv; A.dlt = dlt;
   A.dp = dp; A.da = da; A.dsigma = dsigma;
-  A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp_dim = m.dp; A.inv = m.inv;
+  A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp_dim = m.dp; A.inv = m.inv; A.Dt = m.Dt;
   const size_t smem = sizeof(float) * (ZT * 3 * m.HD + ZT * m.D + ZT * m.H);
   hipLaunchKernelGGL(enf_prologue_bwd_kernel, dim3((A.BZ + ZT - 1) / ZT), dim3(256), smem, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;

@@ -60,6 +60,7 @@ struct PairBwdArgs {
   const float* lse; const float* dybar; const float* delta;
   float* dlt;
   void* store[ENF_NUM_STORE(2)];        // ENF_S_* buffers (STORE instantiation only)
+  float inv_d;                          // 1 / (true num_hidden)
   const char* wzt; const float* wzb;    // ZF only: per (latent, head) [forward | backward] panels of W_zh, and c_zh
   int B, N, Z, dx, inv, use_window, nsplit;
 };
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         K3_SCHED_FENCE();
       }
 #endif
-      ln_stats<NT>(nh, mu1, r1);
+      ln_stats<NT>(nh, mu1, r1, A.inv_d);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[t][i] = gelu_f(a5[t][i]);
         }
-        ln_stats<NT>(v, mu2, r2);
+        ln_stats<NT>(v, mu2, r2, A.inv_d);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) { dy[t][i] *= ah; s1 += dy[t][i]; s2 = fmaf(dy[t][i], v[t][i], s2); }
-        const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
+        const float m1 = xquad_sum(s1) * A.inv_d, m2 = xquad_sum(s2) * A.inv_d;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           K3_OPAQUE(a5[t]);
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         K3_SCHED_FENCE();
       }
 #endif
-      ln_stats<NT>(v, mu2, r2);
+      ln_stats<NT>(v, mu2, r2, A.inv_d);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dy[t][i] *= ah; s1 += dy[t][i]; s2 = fmaf(dy[t][i], v[t][i], s2); }
-      const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
+      const float m1 = xquad_sum(s1) * A.inv_d, m2 = xquad_sum(s2) * A.inv_d;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         // the pre-activation goes through an opaque copy: otherwise hipcc keeps x^2, the exponent and the sigmoid of
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s1 += dnh[t][i]; s2 = fmaf(dnh[t][i], nht[i], s2); }
       }
-      const float m1 = xquad_sum(s1) * (1.0f / D), m2 = xquad_sum(s2) * (1.0f / D);
+      const float m1 = xquad_sum(s1) * A.inv_d, m2 = xquad_sum(s2) * A.inv_d;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #if ENF_K3_PARK
@@ -844,7 +845,7 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
                                    void* const* store, const char* wzt, const float* wzb, hipStream_t st) {
   PairBwdArgs A;
   const bool zf = !store && wzt && wzb && (size_t)m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
-  A.wzt = wzt; A.wzb = wzb;
+  A.wzt = wzt; A.wzb = wzb; A.inv_d = 1.0f / (float)m.Dt;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;
   A.dlt = dlt; A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
   // one workgroup per CU is resident (LDS): split the query tiles over grid.y until all 256 CUs have one

@@ -27,6 +27,7 @@ struct PairFwdArgs {
   const float* lt; const char* blob; EnfLayout L;
   float* ybar; float* lse;
   const char* wz; const float* wzb; const char* wzu;   // z-fold only: per-latent mixer-input panels / biases (enf_wz.hip)
+  float inv_d;                            // 1 / (true num_hidden)
   int xcd_remap;                          // z-fold: 1 when B % 8 == 0 (see the kernel)
   int B, N, Z, dx, inv, use_window, qg;   // qg: query groups per workgroup (1,2,4,8); ZS = 8/qg
 };
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       STAMP(7);
       gelu_tiles<NT, BF16>(acc);
       float mu, rstd;
-      ln_stats<NT>(acc, mu, rstd);
+      ln_stats<NT>(acc, mu, rstd, A.inv_d);
       const float nmr = -mu * rstd;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       STAMP(11 + 4 * h);
       gelu_tiles<NT, BF16>(v);
       float mu, rstd;
-      ln_stats<NT>(v, mu, rstd);
+      ln_stats<NT>(v, mu, rstd, A.inv_d);
       if (active) {
         // softmax over this wave's latents (ECA:141-144).  The rare "logit far above the
         // reference" case rescales the accumulators (wave-uniform branch).
@@ -385,7 +386,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
                                    const float* lt, float* ybar, float* lse, char* wz, float* wzb, char* wzu,
                                    int run_fold, int run_pair, hipStream_t st) {
   PairFwdArgs A;
-  A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu;
+  A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu; A.inv_d = 1.0f / (float)m.Dt;
   A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
   // as many latent splits as there are latents to split (up to 8); the rest of the 8 waves take more queries
   int zs = 1;

@@ -19,6 +19,7 @@ struct TailArgs {
   const float* dout;     // backward
   float* dybar; float* delta; float* act;   // backward outputs + scratch (B*N x (2HD + 2D + 2))
   int NQ, O;             // NQ = B*N queries
+  float inv_hd;          // 1 / (H * true num_hidden)
 };
 
 // row-per-query global <-> acc layout (feature f = 16 t + 4 quad + i lives in tile t register i)
@@ -51,7 +52,7 @@ template <int D, int H, bool BF16> struct TailCfg {
 // SAVE: stash pre-activations + LN stats to `act` (row per query) for the backward chain.
 template <int D, int H, bool BF16, bool SAVE, int NEXT_BYTES>
 DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLayout& L, const float* cst, Pipe& P,
-                      char* ring, unsigned next, int lane, int quad) {
+                      char* ring, unsigned next, int lane, int quad, float inv_hd) {
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
   const float* c_bB = cst, *c_bF1 = cst + HD, *c_bO0 = cst + 2 * HD, *c_bO2 = cst + 2 * HD + D, *c_bO4 = cst + 2 * HD + 2 * D;
@@ -68,7 +69,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[t][i] = gelu_f(a[t][i]);
   float mu, rstd;
-  ln_stats<NTH>(a, mu, rstd);
+  ln_stats<NTH>(a, mu, rstd, inv_hd);
   if (SAVE && quad == 0) { act[T::ACT - 2] = mu; act[T::ACT - 1] = rstd; }
 #pragma unroll
   for (int t = 0; t < NTH; ++t)
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   P.rs2 = P.rs;
   first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
-  tail_forward<D, H, BF16, false, 1024>(o4, A.ybar + (size_t)qi * T::HD, nullptr, A.L, cst, P, ring, NO_STAGE, lane, quad);
+  tail_forward<D, H, BF16, false, 1024>(o4, A.ybar + (size_t)qi * T::HD, nullptr, A.L, cst, P, ring, NO_STAGE, lane, quad, A.inv_hd);
   if (q0 + col < A.NQ) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   P.rs2 = P.rs;
   first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
-  tail_forward<D, H, BF16, true, T::ST_G4>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, lane, quad);
+  tail_forward<D, H, BF16, true, T::ST_G4>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, lane, quad, A.inv_hd);
   // the pre-activations this lane stored are re-read by this lane only (same addresses)
 
   // ---- backward chain
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
         const float nh = (gelu_f(pre[t][i]) - mu) * rstd;
         s1 += a[t][i]; s2 = fmaf(a[t][i], nh, s2);
       }
-    const float m1 = xquad_sum(s1) * (1.0f / HD), m2 = xquad_sum(s2) * (1.0f / HD);
+    const float m1 = xquad_sum(s1) * A.inv_hd, m2 = xquad_sum(s2) * A.inv_hd;
 #pragma unroll
     for (int t = 0; t < NTH; ++t)
 #pragma unroll
@@ -279,7 +280,7 @@ extern "C" int enf_launch_tail(const EnfDims& m, const EnfLayout& L, const char*
   if (m.OB != 1) return ENF_EUNSUPPORTED;
   TailArgs A;
   A.ybar = ybar; A.blob = blob; A.L = L; A.out = out; A.dout = dout; A.dybar = dybar; A.delta = delta; A.act = act;
-  A.NQ = m.B * m.N; A.O = m.O;
+  A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.H * m.Dt);
 #define ENF_CASE(DD, HH)                                                                   \
   if (m.D == DD && m.H == HH) return m.bf16 ? launch_tail<DD, HH, true>(A, bwd != 0, st) : launch_tail<DD, HH, false>(A, bwd != 0, st);
   ENF_CASE(128, 2)

@@ -15,6 +15,7 @@ import torch
 from .. import steerable_attention  # noqa: F401  (package layout parity)
 from ..steerable_attention.invariant import BaseInvariant
 from ... import _lib
+from . import _pad
 
 __all__ = ["EquivariantCrossAttentionNeF", "TENSOR_PATHS"]
 
@@ -83,7 +84,7 @@ class _EnfFunction(torch.autograd.Function):
         s_ = sigma.contiguous() if sigma is not None else None
         dev = p.device
         out = torch.empty((B, N, model.num_out), device=dev, dtype=torch.float32)
-        HD = model.num_heads * model.num_hidden
+        HD = model.num_heads * model._Dp
         ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
         lse = torch.empty((B, N, model.num_heads), device=dev, dtype=torch.float32)
         ws = model._workspace(desc, dev)
@@ -148,6 +149,7 @@ class EquivariantCrossAttentionNeF:
         if precision not in _lib.PREC:
             raise ValueError(f"unknown precision {precision!r}")
         self.num_hidden, self.num_heads, self.num_layers = int(num_hidden), int(num_heads), int(num_layers)
+        self._Dp = _pad.padded_width(self.num_hidden)      # width of the kernels that run it (zero-padded if wider)
         self.num_out, self.latent_dim = int(num_out), int(latent_dim)
         self.cross_attn_invariant = cross_attn_invariant
         self.self_attn_invariant = self_attn_invariant if self_attn_invariant is not None else cross_attn_invariant
@@ -164,8 +166,9 @@ class EquivariantCrossAttentionNeF:
     # ------------------------------------------------------------------ descriptors / buffers
     def _desc(self, B, N, Z):
         inv = self.cross_attn_invariant
-        return _lib.make_desc(B, N, Z, self.num_heads, self.num_hidden, self.latent_dim, self.num_out,
-                              inv.num_x_pos_dims, inv.kernel_id, self.use_gaussian_window, _lib.PREC[self.precision])
+        return _lib.make_desc(B, N, Z, self.num_heads, self._Dp, self.latent_dim, self.num_out,
+                              inv.num_x_pos_dims, inv.kernel_id, self.use_gaussian_window, _lib.PREC[self.precision],
+                              d_true=self.num_hidden if self._Dp != self.num_hidden else 0)
 
     def _workspace(self, desc, device):
         # one cached scratch buffer per (shape, stream); the autograd graph never keeps it alive
@@ -272,6 +275,8 @@ class EquivariantCrossAttentionNeF:
         _lib.check(lib.enf_check_desc(ctypes.byref(desc)))
         ts = [t.detach().to(torch.float32).contiguous() for t in ts]
         self._check_shapes(ts)
+        if self._Dp != self.num_hidden:
+            ts = [t.contiguous() for t in _pad.pad_tensors(ts, self.num_hidden, self._Dp, self.num_heads)]
         nbytes = lib.enf_packed_weight_bytes(ctypes.byref(desc))
         blob = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
         arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -345,7 +350,7 @@ class EquivariantCrossAttentionNeF:
         B, Z, N, dev = p_.shape[0], p_.shape[1], x.shape[1], p_.device
         desc = self._desc(B, N, Z)
         xb, xstride = self._x_arg(x)
-        HD = self.num_heads * self.num_hidden
+        HD = self.num_heads * self._Dp
         out = torch.empty((B, N, self.num_out), device=dev, dtype=torch.float32)
         ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
         lse = torch.empty((B, N, self.num_heads), device=dev, dtype=torch.float32)

@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as Fnn
 
 from ... import _lib
+from . import _pad
 
 LN_EPS = 1e-6          # flax.linen.LayerNorm default (NEF:56, ECA:19)
 STORE_BUDGET_BYTES = 6 << 30   # bound on the materialised activations of one backward chunk
@@ -78,7 +79,7 @@ class _PairFunction(torch.autograd.Function):
         lib = _lib.load()
         B, N, _ = x.shape
         Z = lt.shape[0] // B
-        H, D = model.num_heads, model.num_hidden
+        H, D = model.num_heads, model._Dp
         dev = lt.device
         desc = model._desc(B, N, Z)
         xb, xstride = model._x_arg(x)
@@ -107,7 +108,7 @@ class _PairFunction(torch.autograd.Function):
         model = ctx.model
         xb, lt, blob, ybar, lse = ctx.saved_tensors
         B, N, Z = ctx.dims
-        H, D = model.num_heads, model.num_hidden
+        H, D = model.num_heads, model._Dp
         HD = H * D
         dev = lt.device
         st = _stream(dev)
@@ -158,10 +159,12 @@ class _PairFunction(torch.autograd.Function):
         return (None, dlt, None, gAQ1, gBQ1, gAV1, gBV1, gAF, gBF, gAGB, gBGB, gAM, gBM, None, None)
 
 
-def _ln(x, g, b):
-    mu = x.mean(-1, keepdim=True)
-    var = ((x - mu) ** 2).mean(-1, keepdim=True)
-    return (x - mu) * torch.rsqrt(var + LN_EPS) * g + b
+def _ln(x, g, b, n_true):
+    """LayerNorm over the last axis whose first-n_true-per-block features are real and the rest zero padding
+    (the affine's zero-padded scale / bias clears the padded outputs): statistics divide by n_true."""
+    mu = x.sum(-1, keepdim=True) / n_true
+    var = (x * x).sum(-1, keepdim=True) / n_true - mu * mu
+    return (x - mu) * torch.rsqrt(var.clamp_min(0) + LN_EPS) * g + b
 
 
 def _gelu(x):
@@ -171,14 +174,14 @@ def _gelu(x):
 def latent_table(model, W, p, a, sigma, lay):
     """K1 as differentiable ops: stem, LayerNorm, k / v0, the logit fold (u, c), pose embedding
     and window coefficient, laid out as the pair kernels' latent table (enf_lt_layout)."""
-    H, D = model.num_heads, model.num_hidden
+    H, D = model.num_heads, model._Dp
     B, Z = p.shape[:2]
     inv = model.cross_attn_invariant
     s = a @ W["stem_w"] + W["stem_b"]                                     # NEF:220
-    an = _ln(s, W["lna_g"], W["lna_b"])                                   # NEF:56 / ECB
+    an = _ln(s, W["lna_g"], W["lna_b"], model.num_hidden)                 # NEF:56 / ECB
     k = (an @ W["k_w"] + W["k_b"]).view(B, Z, H, D)                       # ECA:93
     v0 = an @ W["v_w"] + W["v_b"]                                         # ECA:94
-    scale = 1.0 / math.sqrt(D)                                            # ECA:59
+    scale = 1.0 / math.sqrt(model.num_hidden)                             # ECA:59 (the true width, not a padded one)
     qw = W["q_w"].view(D, H, D)
     mu = scale * torch.einsum("ij,jhd->hid", W["rq_w2"], qw)              # (H, D_in, D) : logits = h1 . (mu_h k_h)
     cvec = scale * (torch.einsum("j,jhd->hd", W["rq_b2"], qw) + W["q_b"].view(H, D))
@@ -222,12 +225,12 @@ def effective_pair_params(model, W):
 def tail(model, W, ybar):
     """Everything after the softmax-weighted sum.  The mixer's LayerNorm affine and Dense_1 are
     applied after the sum (attention weights sum to one, so this equals the reference's order)."""
-    H, D = model.num_heads, model.num_hidden
+    H, D = model.num_heads, model._Dp
     B, N, _ = ybar.shape
     y = ybar.view(B, N, H, D) * W["mx_g"] + W["mx_be"]
     y = (y @ W["mx_w1"] + W["mx_b1"]).reshape(B, N, H * D)               # ECA:16-21 (mixer Dense_1)
     y = y @ W["ao_w"] + W["ao_b"]                                         # ECA out_proj
-    f = _ln(_gelu(y @ W["ff_w0"] + W["ff_b0"]), W["ff_g"], W["ff_be"]) @ W["ff_w1"] + W["ff_b1"]
+    f = _ln(_gelu(y @ W["ff_w0"] + W["ff_b0"]), W["ff_g"], W["ff_be"], H * model.num_hidden) @ W["ff_w1"] + W["ff_b1"]
     o = _gelu(f)                                                          # NEF:227-233
     o = _gelu(o @ W["o0_w"] + W["o0_b"])
     o = _gelu(o @ W["o2_w"] + W["o2_b"])
@@ -245,6 +248,8 @@ assert len(W_NAMES) == _lib.ENF_NUM_TENSORS
 
 def apply_train(model, tensors, x, p, a, sigma):
     """nef.apply differentiable w.r.t. every weight tensor and the latents."""
+    if model._Dp != model.num_hidden:      # narrow model: run in the kernels' width (differentiable zero padding)
+        tensors = _pad.pad_tensors(tensors, model.num_hidden, model._Dp, model.num_heads)
     W = dict(zip(W_NAMES, tensors))
     desc = model._desc(p.shape[0], x.shape[1], p.shape[1])
     _lib.check(_lib.load().enf_check_desc(ctypes.byref(desc)))
