@@ -85,3 +85,26 @@ def test_variants_agree_at_full_size(cuda, precision):
     ref, got = outs
     err = float((got - ref).abs().max() / ref.abs().max())
     assert torch.isfinite(got).all() and err < (2e-5 if precision == "f32" else 3e-2), err
+
+
+def test_full_size_invariances(cuda):
+    """Size-independent properties at BASELINE.json's full shape (oracle too slow there): the output is invariant to
+    a permutation of the latent set (softmax over a set, ECA:141) and, for rel_pos_periodic, to shifting any latent
+    or query coordinate by the period 2 (INV/rel_pos_periodic:35-60); both are what the reference eyeballs in
+    _base_pde_trainer.py:731-757."""
+    cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
+    prm = R.init_params(21, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 16, 4096, 64, 22)
+    nef = build_nef(cfg, "f32")
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    tx, tp, ta, ts = t(x), t(p), t(a), t(s)
+    base = nef.apply(params, tx, tp, ta, ts)
+    scale = float(base.abs().max())
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(0)).to(cuda)
+    out = nef.apply(params, tx, tp[:, perm], ta[:, perm], ts[:, perm])
+    assert float((out - base).abs().max()) < 2e-5 * scale          # summation order only
+    shift_p = tp.clone(); shift_p[:, ::2, 0] += 2.0; shift_p[:, 1::3, 1] -= 2.0
+    shift_x = tx.clone(); shift_x[:, ::5, 1] += 2.0
+    out = nef.apply(params, shift_x, shift_p, ta, ts)
+    assert float((out - base).abs().max()) < 5e-4 * scale          # cos/sin(pi (D +- 2)) in fp32
