@@ -62,9 +62,6 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #ifndef ENF_ZFOLD_WAVES
 #define ENF_ZFOLD_WAVES 8
 #endif
-#ifndef ENF_ABL_SAMEPANEL
-#define ENF_ABL_SAMEPANEL 0
-#endif
 #ifndef ENF_ANTIPHASE
 #define ENF_ANTIPHASE false
 #endif
@@ -227,7 +224,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       relu_frags<BF16, KB>(F);
       K2_BIAS(acc, c_bf);
       STAMP(6);
-      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(ENF_ABL_SAMEPANEL ? 0 : z * H * PANEL_DD), active, lane, c_bf);
+      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(z * H * PANEL_DD), active, lane, c_bf);
       else panel_gemm<KB, NT, BF16, ST_GB, NW, K2_INIT>(acc, F, P, ring, pF, pGB, active, lane, c_bf);
       STAMP(7);
       gelu_tiles<NT, BF16>(acc);
@@ -245,7 +242,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
     for (int h = 0; h < H; ++h) {
       f32x4 v[NT];
       if constexpr (ZFOLD) {
-        const unsigned wzh = STAGE_RS2 | (unsigned)(((ENF_ABL_SAMEPANEL ? 0 : z) * H + h) * PANEL_DD);
+        const unsigned wzh = STAGE_RS2 | (unsigned)((z * H + h) * PANEL_DD);
         K2_BIAS(v, zv + H * D + h * D);
         STAMP(10 + 4 * h);
         panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
