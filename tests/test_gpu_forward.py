@@ -108,3 +108,20 @@ def test_full_size_invariances(cuda):
     shift_x = tx.clone(); shift_x[:, ::5, 1] += 2.0
     out = nef.apply(params, shift_x, shift_p, ta, ts)
     assert float((out - base).abs().max()) < 5e-4 * scale          # cos/sin(pi (D +- 2)) in fp32
+
+
+@pytest.mark.parametrize("B,N,Z", [(1, 1, 1), (1, 17, 1), (2, 1, 5), (1, 129, 2)])
+def test_forward_edge_shapes(cuda, B, N, Z):
+    """Degenerate sizes: a single query, a single latent (softmax weight 1), one more query than a tile / a group."""
+    cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=8, O=2)
+    err, _ = run_case(cuda, cfg, B=B, N=N, Z=Z, precision="f32", seed=B + N + Z)
+    assert err < TOL["f32"]
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("invariant", ["polar_periodic", "latitude_periodic"])
+def test_forward_config3_sphere(cuda, invariant, precision):
+    """SURVEY.md 8d config 3 (shallow water / diffusion on the sphere): Z=128 latents, C=32, O=3."""
+    cfg = make_cfg(invariant, D=128, H=2, C=32, O=3, freq=(0.2, 0.4))
+    err, mse = run_case(cuda, cfg, B=2, N=700, Z=128, precision=precision, seed=31)
+    assert err < TOL[precision] and mse < 1e-5
