@@ -28,7 +28,7 @@ def num_store(H):
 class EnfDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("B", "N", "Z", "H", "D", "C", "O", "dx", "invariant_id", "use_window", "precision")] + \
-               [("d_true", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+               [("h_true", ctypes.c_int32), ("d_true", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
 
 class EnfError(RuntimeError):
@@ -100,9 +100,9 @@ def check(rc):
     raise EnfError(f"libenf_hip error {rc}: {msg}")
 
 
-def make_desc(B, N, Z, H, D, C, O, dx, invariant_id, use_window, precision, d_true=0):
+def make_desc(B, N, Z, H, D, C, O, dx, invariant_id, use_window, precision, d_true=0, h_true=0):
     d = EnfDesc()
     d.B, d.N, d.Z, d.H, d.D, d.C, d.O, d.dx = int(B), int(N), int(Z), int(H), int(D), int(C), int(O), int(dx)
     d.invariant_id, d.use_window, d.precision = int(invariant_id), int(bool(use_window)), int(precision)
-    d.d_true = int(d_true)
+    d.d_true, d.h_true = int(d_true), int(h_true)
     return d

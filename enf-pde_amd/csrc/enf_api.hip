@@ -52,7 +52,8 @@ extern "C" int enf_check_desc(const EnfDesc* d) {
   if (two_d && d->dx != 2) return ENF_EDIM;     // reference: assert cfg.num_in == 2 (invariant/__init__.py:62,65)
   if (!(d->D == 64 || d->D == 128)) return ENF_EUNSUPPORTED;
   if (d->d_true < 0 || d->d_true > d->D || (d->d_true & 1)) return ENF_EINVAL;
-  if (!(d->H == 1 || d->H == 2)) return ENF_EUNSUPPORTED;
+  if (!(d->H == 1 || d->H == 2 || (d->H == 4 && d->D == 64))) return ENF_EUNSUPPORTED;   // 4 heads: 64-wide kernels only
+  if (d->h_true < 0 || d->h_true > d->H) return ENF_EINVAL;
   if (d->O > 32) return ENF_EUNSUPPORTED;
   if (d->precision != ENF_PREC_F32 && d->precision != ENF_PREC_BF16) return ENF_EINVAL;
   return ENF_OK;

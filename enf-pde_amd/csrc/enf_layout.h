@@ -27,6 +27,7 @@
 
 struct EnfDims {
   int B, N, Z, H, D, C, O, dx, dp, I, inv, use_window, bf16;
+  int Ht;      // the model's true num_heads (== H unless padded with zero heads)
   int Dt;      // the model's true num_hidden (== D unless zero-padded): LayerNorm divisors, logit scale
   int HD;      // H*D
   int KB;      // D/32   in/out blocks of a D-wide activation
@@ -65,6 +66,7 @@ inline EnfDims enf_dims(const EnfDesc* d) {
   m.dx = d->dx; m.inv = d->invariant_id; m.use_window = d->use_window;
   m.bf16 = d->precision == ENF_PREC_BF16;
   m.Dt = d->d_true > 0 ? d->d_true : d->D;
+  m.Ht = d->h_true > 0 ? d->h_true : d->H;
   m.I = enf_inv_dim(m.inv, m.dx); m.dp = enf_inv_pose_dim(m.inv, m.dx);
   m.HD = m.H * m.D; m.KB = m.D / 32; m.KBH = m.HD / 32; m.OB = (m.O + 31) / 32;
   return m;

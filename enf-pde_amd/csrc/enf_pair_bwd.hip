@@ -59,7 +59,7 @@ struct PairBwdArgs {
   const float* lt; const char* blob; EnfLayout L;
   const float* lse; const float* dybar; const float* delta;
   float* dlt;
-  void* store[ENF_NUM_STORE(2)];        // ENF_S_* buffers (STORE instantiation only)
+  void* store[ENF_NUM_STORE(4)];        // ENF_S_* buffers (STORE instantiation only)
   float inv_d;                          // 1 / (true num_hidden)
   const char* wzt; const float* wzb;    // ZF only: per (latent, head) [forward | backward] panels of W_zh, and c_zh
   int B, N, Z, dx, inv, use_window, nsplit;
@@ -865,6 +865,7 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)
   ENF_CASE(64, 1)
+  ENF_CASE(64, 4)
 #undef ENF_CASE
   return ENF_EUNSUPPORTED;
 }

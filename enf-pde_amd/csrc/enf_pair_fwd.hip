@@ -408,6 +408,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)
   ENF_CASE(64, 1)
+  ENF_CASE(64, 4)
 #undef ENF_CASE
   return ENF_EUNSUPPORTED;
 }

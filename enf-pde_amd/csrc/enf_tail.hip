@@ -280,13 +280,14 @@ extern "C" int enf_launch_tail(const EnfDims& m, const EnfLayout& L, const char*
   if (m.OB != 1) return ENF_EUNSUPPORTED;
   TailArgs A;
   A.ybar = ybar; A.blob = blob; A.L = L; A.out = out; A.dout = dout; A.dybar = dybar; A.delta = delta; A.act = act;
-  A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.H * m.Dt);
+  A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.Ht * m.Dt);
 #define ENF_CASE(DD, HH)                                                                   \
   if (m.D == DD && m.H == HH) return m.bf16 ? launch_tail<DD, HH, true>(A, bwd != 0, st) : launch_tail<DD, HH, false>(A, bwd != 0, st);
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)
   ENF_CASE(64, 1)
+  ENF_CASE(64, 4)
 #undef ENF_CASE
   return ENF_EUNSUPPORTED;
 }

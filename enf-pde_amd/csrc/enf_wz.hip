@@ -193,6 +193,7 @@ extern "C" int enf_launch_wz(const EnfDims& m, const EnfLayout& L, const char* b
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)
   ENF_CASE(64, 1)
+  ENF_CASE(64, 4)
 #undef ENF_CASE
   return ENF_EUNSUPPORTED;
 }

@@ -84,9 +84,9 @@ class _EnfFunction(torch.autograd.Function):
         s_ = sigma.contiguous() if sigma is not None else None
         dev = p.device
         out = torch.empty((B, N, model.num_out), device=dev, dtype=torch.float32)
-        HD = model.num_heads * model._Dp
+        HD = model._Hp * model._Dp
         ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
-        lse = torch.empty((B, N, model.num_heads), device=dev, dtype=torch.float32)
+        lse = torch.empty((B, N, model._Hp), device=dev, dtype=torch.float32)
         ws = model._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.enf_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
@@ -150,6 +150,9 @@ class EquivariantCrossAttentionNeF:
             raise ValueError(f"unknown precision {precision!r}")
         self.num_hidden, self.num_heads, self.num_layers = int(num_hidden), int(num_heads), int(num_layers)
         self._Dp = _pad.padded_width(self.num_hidden)      # width of the kernels that run it (zero-padded if wider)
+        self._Hp = _pad.padded_heads(self.num_heads)       # heads of the kernels that run it (3 -> 4, one zero head)
+        if self._Hp == 4 and self._Dp != 64:
+            raise NotImplementedError("3 or 4 heads are built for num_hidden <= 64 only")
         self.num_out, self.latent_dim = int(num_out), int(latent_dim)
         self.cross_attn_invariant = cross_attn_invariant
         self.self_attn_invariant = self_attn_invariant if self_attn_invariant is not None else cross_attn_invariant
@@ -166,9 +169,10 @@ class EquivariantCrossAttentionNeF:
     # ------------------------------------------------------------------ descriptors / buffers
     def _desc(self, B, N, Z):
         inv = self.cross_attn_invariant
-        return _lib.make_desc(B, N, Z, self.num_heads, self._Dp, self.latent_dim, self.num_out,
+        return _lib.make_desc(B, N, Z, self._Hp, self._Dp, self.latent_dim, self.num_out,
                               inv.num_x_pos_dims, inv.kernel_id, self.use_gaussian_window, _lib.PREC[self.precision],
-                              d_true=self.num_hidden if self._Dp != self.num_hidden else 0)
+                              d_true=self.num_hidden if self._Dp != self.num_hidden else 0,
+                              h_true=self.num_heads if self._Hp != self.num_heads else 0)
 
     def _workspace(self, desc, device):
         # one cached scratch buffer per (shape, stream); the autograd graph never keeps it alive
@@ -275,8 +279,8 @@ class EquivariantCrossAttentionNeF:
         _lib.check(lib.enf_check_desc(ctypes.byref(desc)))
         ts = [t.detach().to(torch.float32).contiguous() for t in ts]
         self._check_shapes(ts)
-        if self._Dp != self.num_hidden:
-            ts = [t.contiguous() for t in _pad.pad_tensors(ts, self.num_hidden, self._Dp, self.num_heads)]
+        if self._Dp != self.num_hidden or self._Hp != self.num_heads:
+            ts = [t.contiguous() for t in _pad.pad_tensors(ts, self.num_hidden, self._Dp, self.num_heads, self._Hp)]
         nbytes = lib.enf_packed_weight_bytes(ctypes.byref(desc))
         blob = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
         arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -350,10 +354,10 @@ class EquivariantCrossAttentionNeF:
         B, Z, N, dev = p_.shape[0], p_.shape[1], x.shape[1], p_.device
         desc = self._desc(B, N, Z)
         xb, xstride = self._x_arg(x)
-        HD = self.num_heads * self._Dp
+        HD = self._Hp * self._Dp
         out = torch.empty((B, N, self.num_out), device=dev, dtype=torch.float32)
         ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
-        lse = torch.empty((B, N, self.num_heads), device=dev, dtype=torch.float32)
+        lse = torch.empty((B, N, self._Hp), device=dev, dtype=torch.float32)
         ws = self._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.enf_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),

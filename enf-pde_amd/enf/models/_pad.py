@@ -21,17 +21,26 @@ def padded_width(D):
     raise NotImplementedError(f"num_hidden={D} exceeds the widest kernel ({KERNEL_WIDTHS[-1]})")
 
 
-def _pad_axis(t, axis, kind, D, Dp, H):
-    if kind is None or D == Dp:
+def padded_heads(H):
+    """num_heads = 3 runs as 4 heads, the fourth all zero (kernels exist for 1, 2 and -- 64-wide only -- 4 heads)."""
+    return 4 if H == 3 else H
+
+
+def _pad_axis(t, axis, kind, D, Dp, H, Hp):
+    if kind is None or (D == Dp and (H == Hp or kind not in ("HD", "2HD"))):
         return t
     axis = axis % t.dim()
     shp = list(t.shape)
 
-    def blocks(nb, width, new_width):          # axis = nb blocks of `width` -> nb blocks of `new_width`
-        v = t.reshape(shp[:axis] + [nb, width] + shp[axis + 1:])
-        pad = [0, 0] * (v.dim() - axis - 2) + [0, new_width - width]
-        v = Fnn.pad(v, pad)
-        return v.reshape(shp[:axis] + [nb * new_width] + shp[axis + 1:])
+    def blocks(nb, width, new_width, groups=1, new_per_group=None):
+        """axis = nb blocks of `width` -> blocks of `new_width`; with groups, each group of nb/groups blocks is
+        extended to new_per_group blocks (zero heads)."""
+        per = nb // groups
+        npg = per if new_per_group is None else new_per_group
+        v = t.reshape(shp[:axis] + [groups, per, width] + shp[axis + 1:])
+        tail = [0, 0] * (v.dim() - axis - 3)
+        v = Fnn.pad(v, tail + [0, new_width - width, 0, npg - per])
+        return v.reshape(shp[:axis] + [groups * npg * new_width] + shp[axis + 1:])
     if kind == "D":
         return blocks(1, D, Dp)
     if kind == "Dh":
@@ -39,9 +48,9 @@ def _pad_axis(t, axis, kind, D, Dp, H):
     if kind == "R":                              # [sin (D/2) | cos (D/2)]
         return blocks(2, D // 2, Dp // 2)
     if kind == "HD":
-        return blocks(H, D, Dp)
+        return blocks(H, D, Dp, 1, Hp)
     if kind == "2HD":                            # [gamma (H, D) | beta (H, D)]
-        return blocks(2 * H, D, Dp)
+        return blocks(2 * H, D, Dp, 2, Hp)
     raise ValueError(kind)
 
 
@@ -54,13 +63,14 @@ AXES = ([(None, "D"), ("D",), ("D",), ("D",)] + _RFF + _RFF + _KB("D", "HD") * 3
 assert len(AXES) == 46
 
 
-def pad_tensors(tensors, D, Dp, H):
-    """The 46 weight tensors (ENF_W_* order) of a width-D model as a width-Dp model."""
-    if D == Dp:
+def pad_tensors(tensors, D, Dp, H, Hp=None):
+    """The 46 weight tensors (ENF_W_* order) of a (width D, H heads) model as a (width Dp, Hp heads) model."""
+    Hp = H if Hp is None else Hp
+    if D == Dp and H == Hp:
         return list(tensors)
     out = []
     for t, kinds in zip(tensors, AXES):
         for ax, kind in enumerate(kinds):
-            t = _pad_axis(t, ax, kind, D, Dp, H)
+            t = _pad_axis(t, ax, kind, D, Dp, H, Hp)
         out.append(t)
     return out

@@ -79,7 +79,7 @@ class _PairFunction(torch.autograd.Function):
         lib = _lib.load()
         B, N, _ = x.shape
         Z = lt.shape[0] // B
-        H, D = model.num_heads, model._Dp
+        H, D = model._Hp, model._Dp
         dev = lt.device
         desc = model._desc(B, N, Z)
         xb, xstride = model._x_arg(x)
@@ -108,7 +108,7 @@ class _PairFunction(torch.autograd.Function):
         model = ctx.model
         xb, lt, blob, ybar, lse = ctx.saved_tensors
         B, N, Z = ctx.dims
-        H, D = model.num_heads, model._Dp
+        H, D = model._Hp, model._Dp
         HD = H * D
         dev = lt.device
         st = _stream(dev)
@@ -174,7 +174,7 @@ def _gelu(x):
 def latent_table(model, W, p, a, sigma, lay):
     """K1 as differentiable ops: stem, LayerNorm, k / v0, the logit fold (u, c), pose embedding
     and window coefficient, laid out as the pair kernels' latent table (enf_lt_layout)."""
-    H, D = model.num_heads, model._Dp
+    H, D = model._Hp, model._Dp
     B, Z = p.shape[:2]
     inv = model.cross_attn_invariant
     s = a @ W["stem_w"] + W["stem_b"]                                     # NEF:220
@@ -225,12 +225,12 @@ def effective_pair_params(model, W):
 def tail(model, W, ybar):
     """Everything after the softmax-weighted sum.  The mixer's LayerNorm affine and Dense_1 are
     applied after the sum (attention weights sum to one, so this equals the reference's order)."""
-    H, D = model.num_heads, model._Dp
+    H, D = model._Hp, model._Dp
     B, N, _ = ybar.shape
     y = ybar.view(B, N, H, D) * W["mx_g"] + W["mx_be"]
     y = (y @ W["mx_w1"] + W["mx_b1"]).reshape(B, N, H * D)               # ECA:16-21 (mixer Dense_1)
     y = y @ W["ao_w"] + W["ao_b"]                                         # ECA out_proj
-    f = _ln(_gelu(y @ W["ff_w0"] + W["ff_b0"]), W["ff_g"], W["ff_be"], H * model.num_hidden) @ W["ff_w1"] + W["ff_b1"]
+    f = _ln(_gelu(y @ W["ff_w0"] + W["ff_b0"]), W["ff_g"], W["ff_be"], model.num_heads * model.num_hidden) @ W["ff_w1"] + W["ff_b1"]
     o = _gelu(f)                                                          # NEF:227-233
     o = _gelu(o @ W["o0_w"] + W["o0_b"])
     o = _gelu(o @ W["o2_w"] + W["o2_b"])
@@ -248,8 +248,8 @@ assert len(W_NAMES) == _lib.ENF_NUM_TENSORS
 
 def apply_train(model, tensors, x, p, a, sigma):
     """nef.apply differentiable w.r.t. every weight tensor and the latents."""
-    if model._Dp != model.num_hidden:      # narrow model: run in the kernels' width (differentiable zero padding)
-        tensors = _pad.pad_tensors(tensors, model.num_hidden, model._Dp, model.num_heads)
+    if model._Dp != model.num_hidden or model._Hp != model.num_heads:      # run in the kernels' shape (differentiable zero padding)
+        tensors = _pad.pad_tensors(tensors, model.num_hidden, model._Dp, model.num_heads, model._Hp)
     W = dict(zip(W_NAMES, tensors))
     desc = model._desc(p.shape[0], x.shape[1], p.shape[1])
     _lib.check(_lib.load().enf_check_desc(ctypes.byref(desc)))

@@ -65,10 +65,12 @@ typedef struct EnfDesc {
   int32_t invariant_id;  /* ENF_INV_* */
   int32_t use_window;    /* use_gaussian_window (NEF:96) */
   int32_t precision;     /* ENF_PREC_* */
+  int32_t h_true;       /* 0, or the model's num_heads when H is padded with all-zero heads (num_heads = 3 runs as H = 4):
+                           only the block FFN's LayerNorm, which normalises over num_heads * num_hidden, needs it */
   int32_t d_true;       /* 0, or the model's num_hidden when D is a zero-padded width (d_true < D): LayerNorm statistics and
                            the D^-1/2 logit scale use d_true; the caller pads every weight tensor with zeros (see
                            enf-pde_amd/enf/models/_pad.py).  Lets num_hidden 16 / 32 (config_diff_sphere.yaml) run on the D = 64 kernels */
-  int32_t reserved[4];
+  int32_t reserved[3];
 } EnfDesc;
 
 /* Weight tensors in the order `enf_pack_weights` expects them; names are the Flax tree of

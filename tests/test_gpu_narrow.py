@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 @pytest.mark.parametrize("D,H,C,O,Z,inv", [(16, 2, 4, 1, 18, "polar_periodic"), (32, 2, 8, 2, 9, "rel_pos_periodic"),
-                                           (16, 1, 4, 1, 8, "ponita"), (48, 2, 8, 1, 6, "rel_pos")])
+                                           (16, 1, 4, 1, 8, "ponita"), (48, 2, 8, 1, 6, "rel_pos"),
+                                           (32, 3, 32, 1, 25, "rel_pos"),       # config_ihc.yaml's width / heads / latents
+                                           (64, 4, 8, 1, 7, "rel_pos_periodic"), (64, 3, 8, 2, 5, "ponita")])
 def test_narrow_forward_backward(cuda, D, H, C, O, Z, inv, precision):
     cfg = make_cfg(inv, D=D, H=H, C=C, O=O, freq=(0.5, 1.0))
     prm = R.init_params(D + Z, cfg, jitter=0.1)
@@ -22,7 +24,7 @@ def test_narrow_forward_backward(cuda, D, H, C, O, Z, inv, precision):
     w = np.random.default_rng(1).standard_normal((3, 50, O))
     ro, rp, ra, rs = ref_grads(prm, cfg, x, p, a, s, w)
     nef = build_nef(cfg, precision)
-    assert nef._Dp == 64
+    assert nef._Dp == 64 and nef._Hp in (1, 2, 4)
     ho, gp, ga, gs = hip_grads(cuda, nef, prm, x, p, a, s, w)
     tol_o, tol_g = (2e-5, 2e-4) if precision == "f32" else (3e-2, 7e-2)
     assert np.abs(ho - ro).max() / np.abs(ro).max() < tol_o
@@ -33,3 +35,8 @@ def test_narrow_forward_backward(cuda, D, H, C, O, Z, inv, precision):
 def test_narrow_weight_grads(cuda):
     cfg = make_cfg("polar_periodic", D=16, H=2, C=4, O=1, freq=(0.5, 1.0))
     WG.check(cuda, cfg, B=3, N=60, Z=18, precision="f32", seed=4)
+
+
+def test_three_heads_weight_grads(cuda):
+    cfg = make_cfg("rel_pos", D=32, H=3, C=8, O=1, freq=(0.5, 1.0))
+    WG.check(cuda, cfg, B=2, N=50, Z=9, precision="f32", seed=6)
