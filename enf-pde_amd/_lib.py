@@ -10,11 +10,11 @@ LIB_PATH = os.environ.get("ENF_HIP_LIB") or os.path.join(_HERE, "libenf_hip.so")
 ENF_NUM_TENSORS = 46
 PREC = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic": 2, "ponita": 3,
-                 "abs_pos": 4, "rel_pos": 5, "norm_rel_pos": 6}
+                 "abs_pos": 4, "rel_pos": 5, "norm_rel_pos": 6, "ball": 7, "ball_lat": 8}
 
 EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
-           "enf_backward_latents", "enf_backward_latents_ex", "enf_forward_stages", "enf_lt_layout", "enf_pack_pair", "enf_pair_forward",
+           "enf_backward_latents", "enf_backward_latents_ex", "enf_forward_stages", "enf_lt_layout", "enf_lt_layout_ext", "enf_pack_pair", "enf_pair_forward",
            "enf_pair_backward", "enf_pair_scratch_bytes", "enf_set_zfold", "enf_set_zfold_bwd", "enf_mse_value_grad"]
 ENF_NUM_PAIR_TENSORS = 12          # ENF_P_* of include/enf_hip.h
 (ENF_S_EQ, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0) = range(8)

@@ -50,6 +50,8 @@ extern "C" int enf_check_desc(const EnfDesc* d) {
   const bool two_d = d->invariant_id == ENF_INV_REL_POS_PERIODIC || d->invariant_id == ENF_INV_PONITA ||
                      d->invariant_id == ENF_INV_LATITUDE_PERIODIC || d->invariant_id == ENF_INV_POLAR_PERIODIC;
   if (two_d && d->dx != 2) return ENF_EDIM;     // reference: assert cfg.num_in == 2 (invariant/__init__.py:62,65)
+  if (enf_inv_has_phase(d->invariant_id) && d->D != 64) return ENF_EUNSUPPORTED;   // (the 128-wide backward kernel has no LDS left)
+  if (enf_inv_has_phase(d->invariant_id) && d->dx != 3) return ENF_EDIM;   // ball, ball_lat: (phi, theta, r) coordinates
   if (!(d->D == 64 || d->D == 128)) return ENF_EUNSUPPORTED;
   if (d->d_true < 0 || d->d_true > d->D || (d->d_true & 1)) return ENF_EINVAL;
   if (!(d->H == 1 || d->H == 2 || (d->H == 4 && d->D == 64))) return ENF_EUNSUPPORTED;   // 4 heads: 64-wide kernels only
@@ -187,6 +189,15 @@ extern "C" int enf_lt_layout(const EnfDesc* d, int* stride, int* off_u, int* off
   if (off_pose) *off_pose = enf_lt_off_pose(d->H, d->D);
   if (off_wcoef) *off_wcoef = enf_lt_off_wcoef(d->H, d->D);
   if (off_c) *off_c = enf_lt_off_c(d->H, d->D);
+  return ENF_OK;
+}
+
+extern "C" int enf_lt_layout_ext(const EnfDesc* d, int* off_ext, int* off_phase_q, int* off_phase_v) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (off_ext) *off_ext = enf_lt_off_ext(d->H, d->D);
+  if (off_phase_q) *off_phase_q = enf_lt_off_phq(d->H, d->D);
+  if (off_phase_v) *off_phase_v = enf_lt_off_phv(d->H, d->D);
   return ENF_OK;
 }
 

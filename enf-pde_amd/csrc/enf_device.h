@@ -462,16 +462,38 @@ DEV QueryPt load_query(const float* xp, int dx, int inv_id) {
   QueryPt q;
   q.x0 = xp[0]; q.x1 = dx > 1 ? xp[1] : 0.f; q.x2 = dx > 2 ? xp[2] : 0.f;
   q.sx = 0.f; q.cx = 0.f;
-  if (inv_id == ENF_INV_LATITUDE_PERIODIC || inv_id == ENF_INV_POLAR_PERIODIC) { q.sx = sinf(q.x1); q.cx = cosf(q.x1); }
+  if (inv_id == ENF_INV_LATITUDE_PERIODIC || inv_id == ENF_INV_POLAR_PERIODIC || enf_inv_has_phase(inv_id)) { q.sx = sinf(q.x1); q.cx = cosf(q.x1); }
   return q;
 }
 
+// `ext`: the latent's 16-float extension (LDS, wave-uniform): ball -> the rotation matrix R (row-major)
 template <bool FAST>
 DEV void pair_invariant(int inv_id, int dx, const QueryPt& q, const f32x4& pz, float wcoef, int use_window,
-                        float (&inv)[4], float& win) {
+                        float (&inv)[4], float& win, const float* ext = nullptr) {
   inv[0] = inv[1] = inv[2] = inv[3] = 0.f;
   win = 0.f;
   switch (inv_id) {
+    case ENF_INV_BALL:                         // ball.py:54-96: [R x^, r_x | r_p -> phase]; window ball.py:36-52
+    case ENF_INV_BALL_LAT: {                   // ball_lat.py:66-88: [th_x, cos dphi, sin dphi, r_x | th_p, r_p -> phase]
+      const float dphi = (q.x0 - pz[0]) * 0.15915494309189535f;
+      const float cd = cos_rev<FAST>(dphi), sd = sin_rev<FAST>(dphi);
+      if (inv_id == ENF_INV_BALL) {
+        const float xr = q.x0 * 0.15915494309189535f;
+        const float xh0 = q.sx * cos_rev<FAST>(xr), xh1 = q.sx * sin_rev<FAST>(xr), xh2 = q.cx;     // unit vector of the query
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(ext), r1 = *reinterpret_cast<const f32x4*>(ext + 4);
+        const float r8 = ext[8];
+        inv[0] = r0[0] * xh0 + r0[1] * xh1 + r0[2] * xh2;
+        inv[1] = r0[3] * xh0 + r1[0] * xh1 + r1[1] * xh2;
+        inv[2] = r1[2] * xh0 + r1[3] * xh1 + r8 * xh2;
+        inv[3] = q.x2;
+      } else { inv[0] = q.x1; inv[1] = cd; inv[2] = sd; inv[3] = q.x2; }
+      if (use_window) {
+        const float dot = q.sx * pz[2] * cd + q.cx * pz[3];
+        const float dc = fminf(fmaxf(dot, -1.f + 1e-6f), 1.f - 1e-6f);
+        const float ang = acosf(dc);
+        win = __expf(-ang * ang * wcoef);
+      }
+    } break;
     case ENF_INV_REL_POS_PERIODIC: {          // rel_pos_periodic.py:47-60; window _base_invariant.py:35-43
       const float d0 = pz[0] - q.x0, d1 = pz[1] - q.x1;
       inv[0] = cos_rev<FAST>(0.5f * d0); inv[1] = cos_rev<FAST>(0.5f * d1);

@@ -44,6 +44,8 @@ ENF_HD inline int enf_inv_dim(int inv, int dx) {
     case ENF_INV_ABS_POS: return dx;
     case ENF_INV_REL_POS: return dx;
     case ENF_INV_NORM_REL_POS: return 1;
+    case ENF_INV_BALL: return 5;
+    case ENF_INV_BALL_LAT: return 6;
     default: return -1;
   }
 }
@@ -56,9 +58,23 @@ ENF_HD inline int enf_inv_pose_dim(int inv, int dx) {
     case ENF_INV_ABS_POS: return dx;
     case ENF_INV_REL_POS: return dx;
     case ENF_INV_NORM_REL_POS: return dx;
+    case ENF_INV_BALL: return 4;              // (alpha, beta, gamma, r)
+    case ENF_INV_BALL_LAT: return 4;
     default: return -1;
   }
 }
+
+// The kernels carry at most 4 invariants per pair.  ball / ball_lat have 5 / 6, but one / two of them depend on the
+// latent only (r_p; th_p and r_p): their contribution coeff[row]^T inv_row to the RFF pre-activation t is a per-latent
+// PHASE vector (D/2 values per RFFNet), which the prologue computes and the pair kernels use as the initial value of
+// the t accumulator -- zero extra work per pair.  Rows of the coefficient matrix, reference order -> [pair rows | latent rows]:
+ENF_HD inline void enf_inv_rows(int inv, int I, int (&pair)[4], int& npair, int (&lat)[2], int& nlat) {
+  npair = 0; nlat = 0;
+  if (inv == ENF_INV_BALL) { pair[0] = 0; pair[1] = 1; pair[2] = 2; pair[3] = 3; npair = 4; lat[0] = 4; nlat = 1; }
+  else if (inv == ENF_INV_BALL_LAT) { pair[0] = 0; pair[1] = 2; pair[2] = 3; pair[3] = 4; npair = 4; lat[0] = 1; lat[1] = 5; nlat = 2; }
+  else { for (int i = 0; i < I && i < 4; ++i) pair[npair++] = i; }
+}
+ENF_HD inline bool enf_inv_has_phase(int inv) { return inv == ENF_INV_BALL || inv == ENF_INV_BALL_LAT; }
 
 inline EnfDims enf_dims(const EnfDesc* d) {
   EnfDims m;
@@ -84,6 +100,7 @@ struct EnfLayout {
   size_t wkt, wvt;   // HD x D: a_to_k / a_to_v kernels transposed, for the prologue backward
   // ---- coefficient A-operands of t = coeff^T inv (fp32 16x16x4 MFMA), [D/32 t-tiles][64 lanes]
   size_t acq, acv;
+  size_t cphq, cphv;   // 2 x D/2: coefficient rows of the latent-only invariants (ball, ball_lat), zero otherwise
   // ---- accumulator-init vectors, fp32
   size_t bq1, bv1, bf, bgb, bm;         // D, D, D, 2HD (panel order), D
   size_t bB, bF1, bO0, bO2, bO4;        // HD, HD, D, D, 32*OB
@@ -120,6 +137,7 @@ inline EnfLayout enf_layout(const EnfDims& m) {
   L.mu = take(f * H * D * D); L.cvec = take(f * H * D);
   L.mut = take(f * H * D * D); L.wkt = take(f * HD * D); L.wvt = take(f * HD * D);
   L.acq = take(f * (D / 32) * 64); L.acv = take(f * (D / 32) * 64);   // D/32 t-tiles x 64 lanes
+  L.cphq = take(f * D); L.cphv = take(f * D);
   L.bq1 = take(f * D); L.bv1 = take(f * D); L.bf = take(f * D); L.bgb = take(f * 2 * HD); L.bm = take(f * D);
   L.bB = take(f * HD); L.bF1 = take(f * HD); L.bO0 = take(f * D); L.bO2 = take(f * D); L.bO4 = take(f * 32 * m.OB);
   const int bf = m.bf16, OP = 32 * m.OB;
@@ -147,7 +165,13 @@ inline EnfLayout enf_layout(const EnfDims& m) {
 
 // ---- latent table: one row per (b, z), written by the prologue, read by the pair kernels
 // [ u (H*D) | v0 (H*D) | pose (4) | wcoef (1) | pad (3) | c (H) | pad ] fp32, 16-byte aligned fields
-ENF_HD inline int enf_lt_stride(int H, int D) { return ((2 * H * D + 8 + H) + 63) & ~63; }
+// [ u (H*D) | v0 (H*D) | pose (4) | wcoef (1) | pad (3) | c (H <= 4) | pad | ext (16) | phase_q (D/2) | phase_v (D/2) ]
+// ext: ball -> the rotation matrix R (9, row-major); in the GRADIENT table: d R (9), then d(latent-only invariants) (2).
+// phase_*: the per-latent RFF phase vectors of ball / ball_lat (zeros are never read for the other invariants).
+ENF_HD inline int enf_lt_off_ext(int H, int D) { return 2 * H * D + 16; }
+ENF_HD inline int enf_lt_off_phq(int H, int D) { return 2 * H * D + 32; }
+ENF_HD inline int enf_lt_off_phv(int H, int D) { return 2 * H * D + 32 + D / 2; }
+ENF_HD inline int enf_lt_stride(int H, int D) { return ((2 * H * D + 32 + D) + 63) & ~63; }
 ENF_HD inline int enf_lt_off_u(int, int) { return 0; }
 ENF_HD inline int enf_lt_off_v0(int H, int D) { return H * D; }
 ENF_HD inline int enf_lt_off_pose(int H, int D) { return 2 * H * D; }

@@ -62,6 +62,16 @@ __global__ void coef_frag_kernel(float* dst, const float* coeff, int I, int Dh /
   dst[idx] = c < I ? coeff[(size_t)c * Dh + t] : 0.f;
 }
 
+// coefficient rows in kernel order: dst (8 x Dh) = [the <= 4 per-pair rows | the <= 2 latent-only rows | 0] (enf_inv_rows)
+__global__ void coef_perm_kernel(float* dst, const float* coeff, int inv, int I, int Dh) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (t >= Dh) return;
+  int pair[4], lat[2], np, nl;
+  enf_inv_rows(inv, I, pair, np, lat, nl);
+  const int src = r < 4 ? (r < np ? pair[r] : -1) : (r - 4 < nl ? lat[r - 4] : -1);
+  dst[(size_t)r * Dh + t] = src >= 0 ? coeff[(size_t)src * Dh + t] : 0.f;
+}
+
 // ---------------------------------------------------------------- MFMA A-operand panel packer
 // A[r][k] (R x K; R multiple of 16, K multiple of 32) = scale * (trans ? W[r*ldw + k] : W[k*ldw + r]).
 // bf16 (v_mfma_f32_16x16x32_bf16): byte ((mt*KB+blk)*64+lane)*16 + 2j
@@ -145,10 +155,20 @@ static int pack_pair_panels(hipStream_t st, char* blob, const EnfLayout& L, cons
   const int D = m.D, H = m.H, HD = m.HD, I = m.I, bf = m.bf16;
   int rc;
   {
+    // coefficient rows permuted to [per-pair rows | latent-only rows] (identity except for ball / ball_lat)
+    float* cq = reinterpret_cast<float*>(blob + L.p_tmp);
+    float* cv = cq + 8 * (D / 2);
+    hipLaunchKernelGGL(coef_perm_kernel, dim3((D / 2 + 63) / 64, 8), dim3(64), 0, st, cq, coefq, m.inv, I, D / 2);
+    hipLaunchKernelGGL(coef_perm_kernel, dim3((D / 2 + 63) / 64, 8), dim3(64), 0, st, cv, coefv, m.inv, I, D / 2);
     const int tot = (D / 32) * 64;
-    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<float*>(blob + L.acq), coefq, I, D / 2);
-    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<float*>(blob + L.acv), coefv, I, D / 2);
+    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<float*>(blob + L.acq), cq, 4, D / 2);
+    hipLaunchKernelGGL(coef_frag_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<float*>(blob + L.acv), cv, 4, D / 2);
     if (hipGetLastError() != hipSuccess) return ENF_ELAUNCH;
+    if (hipMemcpyAsync(blob + L.cphq, cq + 4 * (D / 2), sizeof(float) * D, hipMemcpyDeviceToDevice, st) != hipSuccess) return ENF_ELAUNCH;
+    if (hipMemcpyAsync(blob + L.cphv, cv + 4 * (D / 2), sizeof(float) * D, hipMemcpyDeviceToDevice, st) != hipSuccess) return ENF_ELAUNCH;
+    // d inv[c] = sum_t 2 pi coeff[c][t] d t[t]  (RFF:92), rows in the same order (latent-only rows 4, 5)
+    if ((rc = pack_panel(st, blob, L.gcq, cq, D / 2, 16, D / 2, 1, bf, 8, D / 2, 6.283185307179586f))) return rc;
+    if ((rc = pack_panel(st, blob, L.gcv, cv, D / 2, 16, D / 2, 1, bf, 8, D / 2, 6.283185307179586f))) return rc;
   }
   if ((rc = pack_panel(st, blob, L.aq1, aq1, D, D, D, 0, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.av1, av1, D, D, D, 0, bf))) return rc;
@@ -161,9 +181,6 @@ static int pack_pair_panels(hipStream_t st, char* blob, const EnfLayout& L, cons
   for (int h = 0; h < H; ++h)   // one K-slice (that head's [g g b b ..] 2D columns) per head
     if ((rc = pack_panel(st, blob, L.ggb + (size_t)h * enf_panel_bytes(D, 2 * D, bf), agb + h * 2 * D, 2 * HD, D, 2 * D, 1, bf))) return rc;
   if ((rc = pack_panel(st, blob, L.gm, am, D, D, D, 1, bf))) return rc;
-  // d inv[c] = sum_t 2 pi coeff[c][t] d t[t]  (RFF:92)
-  if ((rc = pack_panel(st, blob, L.gcq, coefq, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
-  if ((rc = pack_panel(st, blob, L.gcv, coefv, D / 2, 16, D / 2, 1, bf, I, D / 2, 6.283185307179586f))) return rc;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
   hipLaunchKernelGGL(wz_const_kernel, dim3((D + 63) / 64, D, H), dim3(64), 0, st, F(L.p_wbmt), F(L.p_wbm), F(L.p_cb), F(L.p_opbg), agb,
                      F(L.bgb), am, F(L.bm), H, D);
@@ -434,15 +451,30 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
       float q[4] = {0.f, 0.f, 0.f, 0.f};
       float wc;
       const float sg = A.sigma ? A.sigma[r] : 1.f;
+      const bool sphere = A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC || enf_inv_has_phase(A.inv);
       if (A.inv == ENF_INV_PONITA) { q[0] = pp[0]; q[1] = pp[1]; q[2] = cosf(pp[2]); q[3] = sinf(pp[2]); }
-      else if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) {
-        q[0] = pp[0]; q[1] = pp[1]; q[2] = sinf(pp[1]); q[3] = cosf(pp[1]);
-      } else { for (int i = 0; i < A.dp && i < 3; ++i) q[i] = pp[i]; }
-      if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) wc = 1.f / (2.f * sg * sg);
-      else wc = 1.f / (sg * sg);
+      else if (sphere) { q[0] = pp[0]; q[1] = pp[1]; q[2] = sinf(pp[1]); q[3] = cosf(pp[1]); }    // ball: (alpha, beta) play (phi, theta) in the window
+      else { for (int i = 0; i < A.dp && i < 3; ++i) q[i] = pp[i]; }
+      wc = sphere ? 1.f / (2.f * sg * sg) : 1.f / (sg * sg);
       float* o = A.lt + (size_t)r * stride;
       for (int i = 0; i < 4; ++i) o[enf_lt_off_pose(H, D) + i] = q[i];
       o[enf_lt_off_wcoef(H, D)] = wc;
+      if (enf_inv_has_phase(A.inv)) {
+        float lat[2] = {0.f, 0.f};
+        if (A.inv == ENF_INV_BALL) {            // R(alpha, beta, gamma), ball.py:76-84; latent-only invariant r_p
+          const float ca = cosf(pp[0]), sa = sinf(pp[0]), cb = cosf(pp[1]), sb = sinf(pp[1]), cg = cosf(pp[2]), sg2 = sinf(pp[2]);
+          float* R = o + enf_lt_off_ext(H, D);
+          R[0] = ca * cb; R[1] = ca * sb * sg2 - sa * cg; R[2] = ca * sb * cg + sa * sg2;
+          R[3] = sa * cb; R[4] = sa * sb * sg2 + ca * cg; R[5] = sa * sb * cg - ca * sg2;
+          R[6] = -sb;     R[7] = cb * sg2;                R[8] = cb * cg;
+          lat[0] = pp[3];
+        } else { lat[0] = pp[1]; lat[1] = pp[3]; }      // ball_lat: th_p, r_p
+        const float* cq = W(A.L.cphq), *cv = W(A.L.cphv);
+        for (int j = 0; j < D / 2; ++j) {               // phase in revolutions (the kernels' sin/cos take 2 pi t)
+          o[enf_lt_off_phq(H, D) + j] = lat[0] * cq[j] + lat[1] * cq[D / 2 + j];
+          o[enf_lt_off_phv(H, D) + j] = lat[0] * cv[j] + lat[1] * cv[D / 2 + j];
+        }
+      }
     }
   }
 }
@@ -560,13 +592,26 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
       const float* g = A.dlt + (size_t)r * stride + enf_lt_off_pose(H, D);
       const float* pp = A.p + (size_t)r * A.dp_dim;
       float* o = A.dp + (size_t)r * A.dp_dim;
+      const bool sph = A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC || enf_inv_has_phase(A.inv);
       if (A.inv == ENF_INV_PONITA) { o[0] = g[0]; o[1] = g[1]; o[2] = -sinf(pp[2]) * g[2] + cosf(pp[2]) * g[3]; }
-      else if (A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC) {
-        o[0] = g[0]; o[1] = g[1] + cosf(pp[1]) * g[2] - sinf(pp[1]) * g[3];
-      } else { for (int i = 0; i < A.dp_dim && i < 3; ++i) o[i] = g[i]; }
+      else if (sph) { o[0] = g[0]; o[1] = g[1] + cosf(pp[1]) * g[2] - sinf(pp[1]) * g[3]; }
+      else { for (int i = 0; i < A.dp_dim && i < 3; ++i) o[i] = g[i]; }
+      if (enf_inv_has_phase(A.inv)) {
+        const float* e = A.dlt + (size_t)r * stride + enf_lt_off_ext(H, D);     // d R (9) | d(latent-only invariants) (2)
+        if (A.inv == ENF_INV_BALL) {
+          const float ca = cosf(pp[0]), sa = sinf(pp[0]), cb = cosf(pp[1]), sb = sinf(pp[1]), cg = cosf(pp[2]), sg2 = sinf(pp[2]);
+          // chain rule through R(alpha, beta, gamma)
+          o[0] += e[0] * (-sa * cb) + e[1] * (-sa * sb * sg2 - ca * cg) + e[2] * (-sa * sb * cg + ca * sg2) +
+                  e[3] * (ca * cb) + e[4] * (ca * sb * sg2 - sa * cg) + e[5] * (ca * sb * cg + sa * sg2);
+          o[1] += e[0] * (-ca * sb) + e[1] * (ca * cb * sg2) + e[2] * (ca * cb * cg) + e[3] * (-sa * sb) + e[4] * (sa * cb * sg2) +
+                  e[5] * (sa * cb * cg) + e[6] * (-cb) + e[7] * (-sb * sg2) + e[8] * (-sb * cg);
+          o[2] = e[1] * (ca * sb * cg + sa * sg2) + e[2] * (-ca * sb * sg2 + sa * cg) + e[4] * (sa * sb * cg - ca * sg2) +
+                 e[5] * (-sa * sb * sg2 - ca * cg) + e[7] * (cb * cg) + e[8] * (-cb * sg2);
+          o[3] = e[9];
+        } else { o[1] += e[9]; o[2] = 0.f; o[3] = e[10]; }
+      }
       const float sg = A.sigma ? A.sigma[r] : 1.f;
       const float dwc = A.dlt[(size_t)r * stride + enf_lt_off_wcoef(H, D)];
-      const bool sph = A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC;
       A.dsigma[r] = (sph ? -1.f : -2.f) / (sg * sg * sg) * dwc;
     }
   }

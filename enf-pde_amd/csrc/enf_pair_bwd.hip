@@ -109,7 +109,12 @@ template <int D, int H, bool BF16> struct PairBwdSmem {
   static constexpr int GC_BYTES = PanelCfg<D / 64, 1, BF16>::BYTES;
   static constexpr int ZVEC = GC + 2 * GC_BYTES;                           // NWAVES x 2HD floats
   static constexpr int LACC = ZVEC + 4 * NWAVES * 2 * H * D;               // NWAVES x (2 H D/16) x 64 lanes floats: dU | dV0 partial sums
-  static constexpr int TOTAL = LACC + (ENF_K3_LDSACC ? 4 * NWAVES * 2 * H * (D / 16) * 64 : 0);
+  // ball / ball_lat: NWAVES x 11 x 16 floats, per-column partial sums of d R (9, quad-0 lanes) and of the two latent-only
+  // invariants' gradients (quad-1 lanes)
+  static constexpr int EXTACC = LACC + (ENF_K3_LDSACC ? 4 * NWAVES * 2 * H * (D / 16) * 64 : 0);
+  static constexpr bool EXT_OK = D == 64;            // the 128-wide kernels have no LDS left: ball needs D = 64 (enf_check_desc)
+  static constexpr int TOTAL = EXTACC + (EXT_OK ? 4 * NWAVES * 11 * 16 : 0);
+  static_assert(TOTAL <= 160 * 1024, "K3 LDS budget");
 };
 
 // d t = d E_sin * E_cos - d E_cos * E_sin   (the 2 pi is folded into the gc panel)
@@ -179,7 +184,7 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
 template <bool FAST>
 DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& pz, float wcoef, int use_window,
                             const float (&inv)[4], float win, float (&dinv)[4], float dwin, float (&dpose)[4],
-                            float& dwc) {
+                            float& dwc, float* dR = nullptr) {
   const float PI = 3.14159265358979323846f;
   switch (inv_id) {
     case ENF_INV_REL_POS_PERIODIC: {
@@ -191,6 +196,8 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
       dpose[0] += PI * (-inv[2] * dinv[0] + inv[0] * dinv[2]);   // d/dD0 [cos pi D0, sin pi D0], D = p - x
       dpose[1] += PI * (-inv[3] * dinv[1] + inv[1] * dinv[3]);
     } break;
+    case ENF_INV_BALL:                 // inv = [R x^ (3), r_x]: d R[i][j] += dinv[i] x^[j]   (dR: 9 per-lane sums)
+    case ENF_INV_BALL_LAT:             // inv = [th_x, cd, sd, r_x]; th_p and r_p are latent-only rows (the phase)
     case ENF_INV_LATITUDE_PERIODIC:
     case ENF_INV_POLAR_PERIODIC: {
       const float dphi = (q.x0 - pz[0]) * 0.15915494309189535f;
@@ -198,6 +205,15 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
       const float dot = q.sx * pz[2] * cd + q.cx * pz[3];
       float ddot = 0.f, dcd = 0.f, dsd = 0.f;
       if (inv_id == ENF_INV_LATITUDE_PERIODIC) { dpose[1] += dinv[1]; dcd += dinv[2]; dsd += dinv[3]; }
+      else if (inv_id == ENF_INV_BALL_LAT) { dcd += dinv[1]; dsd += dinv[2]; }
+      else if (inv_id == ENF_INV_BALL) {
+        const float xr = q.x0 * 0.15915494309189535f;
+        const float xh[3] = {q.sx * cos_rev<FAST>(xr), q.sx * sin_rev<FAST>(xr), q.cx};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) dR[3 * i + j] = dinv[i] * xh[j];
+      }
       else ddot += dinv[0];
       if (use_window) {                                   // win = exp(-ang^2 wc), ang = acos(clip(dot))
         const float dc = fminf(fmaxf(dot, -1.f + 1e-6f), 1.f - 1e-6f);
@@ -303,6 +319,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   float cz[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) cz[h] = ltrow[enf_lt_off_c(H, D) + h];
+  // ball / ball_lat: the latent's rotation matrix and RFF phases (read from the table row: L1/L2 hits), and the
+  // per-column partial sums of their gradients
+  const bool has_ph = SM::EXT_OK && enf_inv_has_phase(A.inv);
+  const float* ext = ltrow + enf_lt_off_ext(H, D);
+  const float* phq = has_ph ? ltrow + enf_lt_off_phq(H, D) : nullptr;
+  const float* phv = has_ph ? ltrow + enf_lt_off_phv(H, D) : nullptr;
+  float* eacc = reinterpret_cast<float*>(smem + SM::EXTACC) + wave * (11 * 16) + col;
+  if (has_ph) {
+    if (quad == 0) { for (int k = 0; k < 9; ++k) eacc[k * 16] = 0.f; }
+    else if (quad == 1) { eacc[9 * 16] = 0.f; eacc[10 * 16] = 0.f; }
+  }
 
   const unsigned pQ1 = (unsigned)A.L.aq1, pV1 = (unsigned)A.L.av1, pF = (unsigned)A.L.af, pGB = (unsigned)A.L.agb,
                  pM = (unsigned)A.L.am, gQ1 = (unsigned)A.L.gq1, gV1 = (unsigned)A.L.gv1, gF = (unsigned)A.L.gf,
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     const size_t qrow = (size_t)b * A.N + n;
     const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
     float inv[4], win;
-    pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win);
+    pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, ext);
     const size_t srow = (size_t)bzc * A.N + n;        // row of the materialised activations (STORE)
     const bool swrite = STORE && nvalid && active;
 
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     Frags<BF16, KB> F;
     {
       f32x4 acc[NT];
-      rff_embed<D, BF16>(acc, inv, c_acq, lane, quad);
+      rff_embed<D, BF16>(acc, inv, c_acq, lane, quad, phq);
       make_frags<BF16, KB>(F, acc);
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pQ1, pV1, true, lane, c_bq1);
 #pragma unroll
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 a3[NT], nh[NT];
 #endif
       f32x4 acc[NT];
-      rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
+      rff_embed<D, BF16>(acc, inv, c_acv, lane, quad, phv);
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EV], srow, D, F, quad);
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pV1, pF, true, lane, c_bv1);
@@ -678,6 +705,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     BSTAMP(15);
     // ---------------- LN / gelu backward -> d a3 -> AF -> relu -> W1v -> d E_v -> d t_v -> d inv
     float dinv[4] = {0.f, 0.f, 0.f, 0.f};
+    float dlat[2] = {0.f, 0.f};           // ball / ball_lat: gradient rows 4, 5 of the gc panels (quad-1 lanes)
     {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -716,7 +744,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA2], srow, D, F, quad);
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO>(acc, F, P, ring, gV1, pQ1, true, lane);                 // d E_v
       f32x4 Ev[NT];
-      rff_embed<D, BF16>(Ev, inv, c_acv, lane, quad);                                                            // recomputed
+      rff_embed<D, BF16>(Ev, inv, c_acv, lane, quad, phv);                                                           // recomputed
       f32x4 dT[TT];
       rff_embed_bwd<D>(dT, acc, Ev);
       Frags<BF16, D / 64> FT;
@@ -724,13 +752,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 di[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       gemm_stage<BF16, D / 64, 1>(di, FT, gcv, lane);
       if (quad == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
+      else if (quad == 1) { dlat[0] += di[0][0]; dlat[1] += di[0][1]; }
     }
     BSTAMP(16);
     // ---------------- q-branch: recompute a1 (transposed, for the relu mask of d h1) and its flipped
     // twin h1f (rows = queries) for d u[f] += sum_n dlogit[n] h1f[n][f]
     {
       f32x4 E[NT];
-      rff_embed<D, BF16>(E, inv, c_acq, lane, quad);
+      rff_embed<D, BF16>(E, inv, c_acq, lane, quad, phq);
       make_frags<BF16, KB>(F, E);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EQ], srow, D, F, quad);
       f32x4 acc[NT];
@@ -781,6 +810,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 di[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       gemm_stage<BF16, D / 64, 1>(di, FT, gcq, lane);
       if (quad == 0) { dinv[0] += di[0][0]; dinv[1] += di[0][1]; dinv[2] += di[0][2]; dinv[3] += di[0][3]; }
+      else if (quad == 1) { dlat[0] += di[0][0]; dlat[1] += di[0][1]; }
     }
     BSTAMP(17);
     // ---------------- per-latent scalars (each column is counted once: quad 0)
@@ -788,8 +818,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       float dwin = 0.f;
 #pragma unroll
       for (int h = 0; h < H; ++h) { dC[h] += dlogit[h]; dwin += dlogit[h]; }
+      if (has_ph) {
+        float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, dR);
+        if (A.inv == ENF_INV_BALL) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) eacc[k * 16] += dR[k];
+        }
+      } else
       pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc);
-    }
+    } else if (has_ph && quad == 1) { eacc[9 * 16] += dlat[0]; eacc[10 * 16] += dlat[1]; }
   }
 
   // ---- fold the partial sums and add this wave's share into the latent-table gradient
@@ -822,6 +860,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
     for (int i = 0; i < 4; ++i) atomicAdd(drow + enf_lt_off_pose(H, D) + i, sc[H + i]);
     atomicAdd(drow + enf_lt_off_wcoef(H, D), sc[H + 4]);
+  }
+  if (has_ph) {            // d R (9) | d(latent-only invariants) (2) -> the gradient row's ext field
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      float a = quad == (k < 9 ? 0 : 1) ? eacc[k * 16] : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if (lane == 0) atomicAdd(drow + enf_lt_off_ext(H, D) + k, a);
+    }
   }
 }
 

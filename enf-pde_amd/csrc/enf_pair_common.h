@@ -47,13 +47,15 @@ DEV void gb_panel(f32x4 (&v)[D / 16], f32x4 (&opg)[KEEP ? D / 16 : 1], const Fra
 
 // RFF encoding of this lane's pair: E[0..D/32) = sin(2 pi t), E[D/32..D/16) = cos(2 pi t),
 // t = coeff^T inv by one fp32 MFMA per 16 t-values (K = 4 = the invariant components)   RFF:86-93
+// `phase` (fp32 in LDS, D/2 values, or nullptr): the per-latent part of t for invariants with latent-only components
 template <int D, bool BF16>
-DEV void rff_embed(f32x4 (&E)[D / 16], const float (&inv)[4], const float* cfrag, int lane, int quad) {
+DEV void rff_embed(f32x4 (&E)[D / 16], const float (&inv)[4], const float* cfrag, int lane, int quad, const float* phase = nullptr) {
   constexpr int TT = D / 32;
   const float bq = quad == 0 ? inv[0] : quad == 1 ? inv[1] : quad == 2 ? inv[2] : inv[3];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (phase) t = *reinterpret_cast<const f32x4*>(phase + 16 * tt + 4 * quad);
     t = __builtin_amdgcn_mfma_f32_16x16x4f32(cfrag[tt * 64 + lane], bq, t, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { E[tt][i] = sin_rev<BF16>(t[i]); E[TT + tt][i] = cos_rev<BF16>(t[i]); }

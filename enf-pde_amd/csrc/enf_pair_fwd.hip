@@ -171,13 +171,14 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     float inv[4], win;
-    pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win);
+    const bool has_ph = D == 64 && enf_inv_has_phase(A.inv);   // ball / ball_lat (64-wide only): rotation matrix and RFF phases of the latent
+    pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, ltrow + enf_lt_off_ext(H, D));
 
     float logit[H];
     Frags<BF16, KB> F;
     {  // ---------------- query branch
       f32x4 acc[NT];
-      rff_embed<D, BF16>(acc, inv, c_acq, lane, quad);
+      rff_embed<D, BF16>(acc, inv, c_acq, lane, quad, has_ph ? ltrow + enf_lt_off_phq(H, D) : nullptr);
       make_frags<BF16, KB>(F, acc);
       K2_BIAS(acc, c_bq1);
       STAMP(1);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
     STAMP(3);
     {  // ---------------- value branch: RFFNet layer, folded (linear_final . Dense_0), gelu, LN
       f32x4 acc[NT];
-      rff_embed<D, BF16>(acc, inv, c_acv, lane, quad);
+      rff_embed<D, BF16>(acc, inv, c_acv, lane, quad, has_ph ? ltrow + enf_lt_off_phv(H, D) : nullptr);
       make_frags<BF16, KB>(F, acc);
       K2_BIAS(acc, c_bv1);
       STAMP(4);

@@ -7,7 +7,7 @@ import math
 
 import torch
 
-from .utils import init_positions_grid, init_positions_polar, init_ori_rotation_invariant_s2
+from .utils import init_positions_grid, init_positions_polar, init_positions_ball, init_ori_rotation_invariant_s2
 
 
 class PositionOrientationFeatureAutodecoder:
@@ -30,7 +30,8 @@ class PositionOrientationFeatureAutodecoder:
             k = int(round((Z // 2) ** (1.0 / d), 5))
             gw = d * math.pi / k                                         # autodecoder.py:45-51
         elif self.coordinate_system == "ball":
-            raise NotImplementedError("'ball' latents (IHC experiment) are outside the accelerated path")
+            p_pos = init_positions_ball(S, Z)
+            gw = 1.0                                                     # autodecoder.py:53-54
         else:
             raise ValueError(f"unknown coordinate system {self.coordinate_system}")
         P = {"p_pos": p_pos}

@@ -30,3 +30,13 @@ def init_ori_rotation_invariant_s2(num_signals, num_latents, num_dims):
     """One orientation per latent, atan2(pos0, pos1) (utils.py:106-109)."""
     pos = init_positions_grid(num_signals, num_latents, num_dims)
     return torch.atan2(pos[:, :, 0], pos[:, :, 1])[:, :, None]
+
+
+def init_positions_ball(num_signals, num_latents):
+    """Euler angles (alpha, beta, gamma) on a Fibonacci lattice plus the radius 0.75 (utils.py:4-33): shape (S, Z, 4)."""
+    i = torch.arange(1, num_latents + 1, dtype=torch.float32)
+    alpha = torch.arccos(1 - 2 * i / (num_latents + 1))
+    beta = (math.pi * (1 + 5 ** 0.5)) * i
+    gamma = torch.arange(num_latents, dtype=torch.float32) * (2 * math.pi / num_latents)
+    pos = torch.stack([alpha, beta, gamma, torch.full_like(alpha, 0.75)], dim=-1)
+    return pos[None].repeat(num_signals, 1, 1)

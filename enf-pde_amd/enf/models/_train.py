@@ -36,7 +36,11 @@ def lt_layout(desc):
     lib = _lib.load()
     v = [ctypes.c_int(0) for _ in range(6)]
     _lib.check(lib.enf_lt_layout(ctypes.byref(desc), *[ctypes.byref(t) for t in v]))
-    return dict(zip(("stride", "u", "v0", "pose", "wcoef", "c"), [t.value for t in v]))
+    lay = dict(zip(("stride", "u", "v0", "pose", "wcoef", "c"), [t.value for t in v]))
+    e = [ctypes.c_int(0) for _ in range(3)]
+    _lib.check(lib.enf_lt_layout_ext(ctypes.byref(desc), *[ctypes.byref(t) for t in e]))
+    lay.update(zip(("ext", "phq", "phv"), [t.value for t in e]))
+    return lay
 
 
 SPLIT_K = 4096      # rows per slice of the pair axis: a (D x P)(P x D) product has only D^2/tile^2 output tiles, so the
@@ -191,18 +195,34 @@ def latent_table(model, W, p, a, sigma, lay):
     zero = p.new_zeros(B, Z, 1)
     if name == "ponita":
         pose = torch.cat([p[..., :2], torch.cos(p[..., 2:3]), torch.sin(p[..., 2:3])], -1)
-    elif name in ("latitude_periodic", "polar_periodic"):
+    elif name in ("latitude_periodic", "polar_periodic", "ball", "ball_lat"):
         pose = torch.cat([p[..., :2], torch.sin(p[..., 1:2]), torch.cos(p[..., 1:2])], -1)
     else:
         pose = torch.cat([p[..., :3]] + [zero] * (4 - min(p.shape[-1], 3)), -1)
     if sigma is None:
         wc = p.new_ones(B, Z, 1)
-    elif name in ("latitude_periodic", "polar_periodic"):
+    elif name in ("latitude_periodic", "polar_periodic", "ball", "ball_lat"):
         wc = 1.0 / (2.0 * sigma * sigma)
     else:
         wc = 1.0 / (sigma * sigma)
-    parts = sorted([(lay["u"], u), (lay["v0"], v0), (lay["pose"], pose), (lay["wcoef"], wc), (lay["c"], c)],
-                   key=lambda t: t[0])
+    parts = [(lay["u"], u), (lay["v0"], v0), (lay["pose"], pose), (lay["wcoef"], wc), (lay["c"], c)]
+    if name in ("ball", "ball_lat"):
+        # ext = [R (9) | latent-only invariants (2)]: the backward kernel returns d R and d(latent-only) in the same slots;
+        # phases = coeff[latent-only rows]^T latent-only invariants, per RFFNet (csrc/enf_layout.h: enf_inv_rows)
+        if name == "ball":
+            al, be, ga = p[..., 0], p[..., 1], p[..., 2]
+            ca, sa, cb, sb, cg, sg = al.cos(), al.sin(), be.cos(), be.sin(), ga.cos(), ga.sin()
+            R = torch.stack([ca * cb, ca * sb * sg - sa * cg, ca * sb * cg + sa * sg,
+                             sa * cb, sa * sb * sg + ca * cg, sa * sb * cg - ca * sg,
+                             -sb, cb * sg, cb * cg], -1)                                # ball.py:76-84
+            lat, rows = torch.stack([p[..., 3], torch.zeros_like(p[..., 3])], -1), [4]
+        else:
+            R = p.new_zeros(B, Z, 9)
+            lat, rows = torch.stack([p[..., 1], p[..., 3]], -1), [1, 5]                 # ball_lat.py:66-88: th_p, r_p
+        ld = lat.detach()[..., :len(rows)]      # the phases' gradient comes back through the ext slots, not the phase slots
+        parts += [(lay["ext"], torch.cat([R, lat], -1)),
+                  (lay["phq"], ld @ W["rq_coef"].detach()[rows]), (lay["phv"], ld @ W["rv_coef"].detach()[rows])]
+    parts = sorted(parts, key=lambda t: t[0])
     out, pos = [], 0
     for off, t in parts:
         if off > pos:

@@ -53,6 +53,8 @@ RelativePosition2DPeriodic = _mk("rel_pos_periodic", lambda nd: 2 * nd, _n, _n, 
 RelativePositionPolarPeriodic = _mk("polar_periodic", _c(1), _c(2), _c(2), 0, True)        # polar_periodic.py:6-33
 RelativeLatitudePeriodic = _mk("latitude_periodic", _c(4), _c(2), _c(2), 0, True)          # spherical_longitude.py:6-32
 PonitaPos2D = _mk("ponita", _c(2), _c(2), _c(2), 1, False)                                 # ponita.py:6-18
+BallInvariant = _mk("ball", _c(5), _c(3), _c(4), 0, False)                                 # ball.py:6-33 (p = Euler angles + radius)
+BallLatInvariant = _mk("ball_lat", _c(6), _c(3), _c(4), 0, False)                          # ball_lat.py:6-33
 for _k, _v in list(globals().items()):
     if isinstance(_v, type) and issubclass(_v, BaseInvariant) and _v is not BaseInvariant:
         _v.__name__ = _v.__qualname__ = _k
@@ -77,8 +79,10 @@ def get_ca_invariant(cfg) -> BaseInvariant:
         return RelativePositionPolarPeriodic()
     if t == "latitude_periodic":
         return RelativeLatitudePeriodic()
-    if t in ("ball", "ball_lat"):
-        raise NotImplementedError(f"invariant '{t}' (IHC experiment) is outside the accelerated path (SURVEY.md 2, row 3)")
+    if t == "ball":
+        return BallInvariant()
+    if t == "ball_lat":
+        return BallLatInvariant()
     raise ValueError(f"Unknown invariant type: {t}.")
 
 

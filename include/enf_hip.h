@@ -39,7 +39,9 @@ enum {
   ENF_INV_ABS_POS = 4,           /* abs_pos.py:42                                                */
   ENF_INV_REL_POS = 5,           /* rel_pos.py:41                                                */
   ENF_INV_NORM_REL_POS = 6,      /* norm_rel_pos.py:34                                           */
-  ENF_INV_COUNT = 7
+  ENF_INV_BALL = 7,              /* ball.py:54-96: [R(alpha,beta,gamma) x^, r_x, r_p], window :36-52 (64-wide kernels only) */
+  ENF_INV_BALL_LAT = 8,          /* ball_lat.py:54-88: [th_x, th_p, cos dphi, sin dphi, r_x, r_p]                              */
+  ENF_INV_COUNT = 9
 };
 
 /* arithmetic of the per-pair contractions */
@@ -173,6 +175,12 @@ enum { ENF_S_EQ = 0, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_D
 #define ENF_NUM_STORE(H) (7 + 4 * (H))
 
 int enf_lt_layout(const EnfDesc* d, int* stride, int* off_u, int* off_v0, int* off_pose, int* off_wcoef, int* off_c);
+/* ball / ball_lat only (invariant/ball.py, ball_lat.py): further fields of a latent-table row.
+ *   ext (16 floats): [ R (9, row-major; ball.py:76-84) | the latent-only invariants (2) | pad ]; in the GRADIENT table the
+ *                    backward returns d R and d(latent-only invariants) in the same slots
+ *   phase_q, phase_v (D/2 each): coeff[latent-only rows]^T (latent-only invariants), the per-latent part of the RFF
+ *                    pre-activation of the query / value RFFNet */
+int enf_lt_layout_ext(const EnfDesc* d, int* off_ext, int* off_phase_q, int* off_phase_v);
 int enf_pack_pair(const EnfDesc* d, const float* const* pair_tensors, void* packed, void* stream);
 /* K2 alone: lt -> ybar (B,N,H*D), lse (B,N,H).  `scratch` (enf_pair_scratch_bytes; may be 0 -> NULL) holds the
  * per-latent folded matrices of the large-N forward variant. */

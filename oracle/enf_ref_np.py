@@ -39,6 +39,8 @@ INVARIANTS = {
     "abs_pos": dict(dim=None, dx=None, z_pos=None, z_ori=0, window="nonperiodic"),   # INV/abs_pos.py:17-25 (dim = num_in)
     "rel_pos": dict(dim=None, dx=None, z_pos=None, z_ori=0, window="nonperiodic"),   # INV/rel_pos.py:17-24
     "norm_rel_pos": dict(dim=1, dx=None, z_pos=None, z_ori=0, window="nonperiodic"), # INV/norm_rel_pos.py:17-22
+    "ball": dict(dim=5, dx=3, z_pos=4, z_ori=0, window="sphere"),                    # INV/ball.py:22-33 (p = Euler angles + radius)
+    "ball_lat": dict(dim=6, dx=3, z_pos=4, z_ori=0, window="sphere"),                # INV/ball_lat.py:22-33
 }
 
 
@@ -143,7 +145,30 @@ def invariant(name, x, p):
         return x[:, :, None, :] - p[:, None, :, :]
     if name == "norm_rel_pos":                      # INV/norm_rel_pos.py:34
         return np.linalg.norm(p[:, None, :, :] - x[:, :, None, :], axis=-1, keepdims=True)
+    if name == "ball":                              # INV/ball.py:54-96: [R(alpha,beta,gamma) x^, r_x, r_p]
+        B, N, Z = x.shape[0], x.shape[1], p.shape[1]
+        xv = _sph_unit(x)                                                       # (B,N,3)
+        R = ball_rotation(p)                                                    # (B,Z,3,3)
+        rot = np.einsum("bzij,bnj->bnzi", R, xv)
+        r_x = np.broadcast_to(x[:, :, None, 2:3], (B, N, Z, 1))
+        r_p = np.broadcast_to(p[:, None, :, 3:4], (B, N, Z, 1))
+        return np.concatenate([rot, r_x, r_p], axis=-1)
+    if name == "ball_lat":                          # INV/ball_lat.py:66-88
+        B, N, Z = x.shape[0], x.shape[1], p.shape[1]
+        e = lambda t: np.broadcast_to(t, (B, N, Z))[..., None]
+        dphi = e(x[:, :, None, 0]) - e(p[:, None, :, 0])
+        return np.concatenate([e(x[:, :, None, 1]), e(p[:, None, :, 1]), np.cos(dphi), np.sin(dphi),
+                               e(x[:, :, None, 2]), e(p[:, None, :, 3])], axis=-1)
     raise ValueError(f"Unknown invariant type: {name}.")
+
+
+def ball_rotation(p):
+    """INV/ball.py:76-84: the 3x3 matrix built from the Euler angles (alpha, beta, gamma) = p[..., :3]."""
+    al, be, ga = p[..., 0], p[..., 1], p[..., 2]
+    ca, sa, cb, sb, cg, sg = np.cos(al), np.sin(al), np.cos(be), np.sin(be), np.cos(ga), np.sin(ga)
+    return np.stack([np.stack([ca * cb, ca * sb * sg - sa * cg, ca * sb * cg + sa * sg], axis=-1),
+                     np.stack([sa * cb, sa * sb * sg + ca * cg, sa * sb * cg - ca * sg], axis=-1),
+                     np.stack([-sb, cb * sg, cb * cg], axis=-1)], axis=-2)
 
 
 def gaussian_window(name, x, p, sigma, num_in=2):
@@ -354,6 +379,12 @@ def init_latents(num_signals, num_latents, latent_dim, invariant_name, coordinat
         out["p_pos"] = init_positions_polar(num_signals, num_latents, d)
         k = int(round((num_latents // 2) ** (1.0 / d), 5))
         gw = d * np.pi / k                                         # AD:46-51
+    elif coordinate_system == "ball":                              # LU:4-33, AD:53-54 (Euler angles on a Fibonacci lattice + radius)
+        i = np.arange(1, num_latents + 1)
+        pos = np.stack([np.arccos(1 - 2 * i / (num_latents + 1)), np.pi * (1 + 5 ** 0.5) * i,
+                        np.arange(num_latents) * (2 * np.pi / num_latents), np.full(num_latents, 0.75)], -1)
+        out["p_pos"] = np.repeat(pos[None], num_signals, axis=0)
+        gw = 1.0
     else:
         raise ValueError(coordinate_system)
     if spec["z_ori"] > 0:                                          # AD:27-29, LU:106-109

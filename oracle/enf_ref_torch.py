@@ -89,6 +89,22 @@ def invariant(name, x, p):
         return x[:, :, None, :] - p[:, None, :, :]
     if name == "norm_rel_pos":
         return (p[:, None, :, :] - x[:, :, None, :]).norm(dim=-1, keepdim=True)
+    if name == "ball":                              # INV/ball.py:54-96
+        B, N, Z = x.shape[0], x.shape[1], p.shape[1]
+        xv = _sph_unit(x)
+        al, be, ga = p[..., 0], p[..., 1], p[..., 2]
+        ca, sa, cb, sb, cg, sg = torch.cos(al), torch.sin(al), torch.cos(be), torch.sin(be), torch.cos(ga), torch.sin(ga)
+        R = torch.stack([torch.stack([ca * cb, ca * sb * sg - sa * cg, ca * sb * cg + sa * sg], dim=-1),
+                         torch.stack([sa * cb, sa * sb * sg + ca * cg, sa * sb * cg - ca * sg], dim=-1),
+                         torch.stack([-sb, cb * sg, cb * cg], dim=-1)], dim=-2)
+        rot = torch.einsum("bzij,bnj->bnzi", R, xv)
+        return torch.cat([rot, x[:, :, None, 2:3].expand(B, N, Z, 1), p[:, None, :, 3:4].expand(B, N, Z, 1)], dim=-1)
+    if name == "ball_lat":                          # INV/ball_lat.py:66-88
+        B, N, Z = x.shape[0], x.shape[1], p.shape[1]
+        e = lambda t: t.expand(B, N, Z)[..., None]
+        dphi = e(x[:, :, None, 0]) - e(p[:, None, :, 0])
+        return torch.cat([e(x[:, :, None, 1]), e(p[:, None, :, 1]), torch.cos(dphi), torch.sin(dphi),
+                          e(x[:, :, None, 2]), e(p[:, None, :, 3])], dim=-1)
     raise ValueError(f"Unknown invariant type: {name}.")
 
 

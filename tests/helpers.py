@@ -5,6 +5,8 @@ from oracle import enf_ref_np as R
 
 
 def make_cfg(invariant="rel_pos_periodic", D=128, H=2, C=16, O=1, num_in=2, freq=(0.05, 0.1), use_window=True):
+    if invariant in ("ball", "ball_lat"):
+        num_in = 3
     return dict(num_hidden=D, num_heads=H, latent_dim=C, num_out=O, invariant=invariant, num_in=num_in,
                 embedding_freq_multiplier=tuple(freq), use_gaussian_window=use_window, num_layers=0,
                 condition_value_transform=True)
@@ -20,6 +22,11 @@ def make_inputs(cfg, B, N, Z, seed=0, sigma_scale=1.0):
         x = np.stack([rng.uniform(0, 2 * np.pi, (B, N)), rng.uniform(0.05, np.pi - 0.05, (B, N))], -1)
         p = np.stack([rng.uniform(0, 2 * np.pi, (B, Z)), rng.uniform(0.2, np.pi - 0.2, (B, Z))], -1)
         sigma = np.full((B, Z, 1), 0.8) * sigma_scale
+    elif name in ("ball", "ball_lat"):        # x = (phi, theta, r); p = Euler angles (alpha, beta, gamma) + radius
+        x = np.stack([rng.uniform(0, 2 * np.pi, (B, N)), rng.uniform(0.05, np.pi - 0.05, (B, N)), rng.uniform(0.1, 1.0, (B, N))], -1)
+        p = np.stack([rng.uniform(0, 2 * np.pi, (B, Z)), rng.uniform(0.2, np.pi - 0.2, (B, Z)),
+                      rng.uniform(0, 2 * np.pi, (B, Z)), rng.uniform(0.5, 1.0, (B, Z))], -1)
+        sigma = np.full((B, Z, 1), 1.0) * sigma_scale
     else:
         x = rng.uniform(-1, 1, (B, N, dx))
         p = rng.uniform(-1, 1, (B, Z, spec["z_pos"]))

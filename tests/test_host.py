@@ -64,13 +64,19 @@ def test_check_desc_and_error_mapping(lib):
     assert lib.enf_packed_weight_bytes(ctypes.byref(unsupported)) == 0
     assert lib.enf_invariant_dim(0, 2) == 4 and lib.enf_invariant_dim(2, 2) == 1 and lib.enf_invariant_dim(4, 3) == 3
     assert lib.enf_invariant_pose_dim(3, 2) == 3
+    assert lib.enf_invariant_dim(7, 3) == 5 and lib.enf_invariant_dim(8, 3) == 6 and lib.enf_invariant_pose_dim(7, 3) == 4
+    # ball / ball_lat: 3-d coordinates, 64-wide kernels only
+    _lib.check(lib.enf_check_desc(ctypes.byref(_lib.make_desc(2, 100, 25, 4, 64, 32, 1, 3, 7, 1, 1))))
+    for bad in (_lib.make_desc(2, 100, 25, 2, 128, 32, 1, 3, 7, 1, 1), _lib.make_desc(2, 100, 25, 4, 64, 32, 1, 2, 8, 1, 1)):
+        with pytest.raises((_lib.EnfError, NotImplementedError, AssertionError)):
+            _lib.check(lib.enf_check_desc(ctypes.byref(bad)))
     # NULL buffers are rejected before anything touches the (absent) GPU
     assert lib.enf_forward(ctypes.byref(ok), None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
 
 
 def test_invariant_factory_mirrors_reference():
     from enf_pde_amd.enf.steerable_attention.invariant import get_ca_invariant, get_sa_invariant
-    for name in ("rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos", "rel_pos", "norm_rel_pos"):
+    for name in ("rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos", "rel_pos", "norm_rel_pos", "ball", "ball_lat"):
         inv = get_ca_invariant(NS(invariant_type=name, num_in=2))
         spec = R.invariant_spec(name, 2)
         assert (inv.dim, inv.num_x_pos_dims, inv.num_z_pos_dims, inv.num_z_ori_dims) == \
@@ -81,8 +87,8 @@ def test_invariant_factory_mirrors_reference():
         get_ca_invariant(NS(invariant_type="bogus", num_in=2))
     with pytest.raises(AssertionError):
         get_ca_invariant(NS(invariant_type="rel_pos_periodic", num_in=3))
-    with pytest.raises(NotImplementedError):
-        get_ca_invariant(NS(invariant_type="ball", num_in=3))
+    assert type(get_ca_invariant(NS(invariant_type="ball", num_in=3))).__name__ == "BallInvariant"
+    assert type(get_ca_invariant(NS(invariant_type="ball_lat", num_in=3))).__name__ == "BallLatInvariant"
 
 
 def _nef(**kw):
@@ -160,6 +166,11 @@ def test_latent_containers_match_reference_init():
     refp = R.init_latents(3, 128, 32, "latitude_periodic", coordinate_system="polar")
     assert np.allclose(pol["params"]["p_pos"].numpy(), refp["p_pos"], atol=1e-6)
     assert np.allclose(pol["params"]["gaussian_window"].numpy(), refp["gaussian_window"], atol=1e-6)
+    ball = PositionOrientationFeatureAutodecoder(2, 25, 32, 4, 0, coordinate_system="ball").init(device="cpu")     # config_ihc.yaml
+    refb = R.init_latents(2, 25, 32, "ball", coordinate_system="ball", num_in=3)
+    assert ball["params"]["p_pos"].shape == (2, 25, 4)
+    assert np.allclose(ball["params"]["p_pos"].numpy(), refb["p_pos"], atol=1e-5)
+    assert np.allclose(ball["params"]["gaussian_window"].numpy(), 1.0)
     pon = PositionOrientationFeatureAutodecoderMeta(1, 16, 8, 2, 1, gaussian_window_size=-1).init(device="cpu")
     assert np.allclose(pon["params"]["p_ori"].numpy(), R.init_latents(1, 16, 8, "ponita")["p_ori"], atol=1e-6)
     pp, _, _ = PositionOrientationFeatureAutodecoderMeta(1, 16, 8, 2, 1, gaussian_window_size=-1).apply(pon)

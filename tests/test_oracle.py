@@ -14,7 +14,8 @@ from tests.helpers import make_cfg, make_inputs
 from tests.golden.make_golden import CASES
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-ALL_INV = ["rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos", "rel_pos", "norm_rel_pos"]
+ALL_INV = ["rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos", "rel_pos", "norm_rel_pos",
+           "ball", "ball_lat"]
 
 
 def small_cfg(inv, **kw):
@@ -124,7 +125,27 @@ def test_latitude_periodic_longitude_shift_only():
     assert np.abs(base - _apply(cfg, prm, x + tilt, p + tilt, a, s)).max() > 1e-6
 
 
-@pytest.mark.parametrize("inv", ["rel_pos_periodic", "ponita", "polar_periodic", "latitude_periodic"])
+def test_ball_invariants_structure():
+    """ball.py:54-96 / ball_lat.py:66-88: R(alpha, beta, gamma) is a rotation; the first three ball invariants are the
+    rotated unit vector of the query; ball_lat only sees the longitude DIFFERENCE."""
+    cfg = small_cfg("ball")
+    x, p, a, s = make_inputs(cfg, 2, 11, 5, 30)
+    Rm = R.ball_rotation(p)
+    assert np.abs(Rm @ np.swapaxes(Rm, -1, -2) - np.eye(3)).max() < 1e-12 and np.allclose(np.linalg.det(Rm), 1.0)
+    inv = R.invariant("ball", x, p)
+    assert inv.shape == (2, 11, 5, 5) and np.abs(np.linalg.norm(inv[..., :3], axis=-1) - 1).max() < 1e-12
+    assert np.array_equal(inv[..., 3], np.broadcast_to(x[:, :, None, 2], inv.shape[:3]))
+    assert np.array_equal(inv[..., 4], np.broadcast_to(p[:, None, :, 3], inv.shape[:3]))
+    cfg = small_cfg("ball_lat")
+    prm = R.init_params(31, cfg, jitter=0.1)
+    base = _apply(cfg, prm, x, p, a, s)
+    sx, sp = np.array([0.9, 0.0, 0.0]), np.array([0.9, 0.0, 0.0, 0.0])
+    assert np.abs(base - _apply(cfg, prm, x + sx, p + sp, a, s)).max() < 1e-9
+    tx, tp = np.array([0.0, 0.2, 0.0]), np.array([0.0, 0.2, 0.0, 0.0])
+    assert np.abs(base - _apply(cfg, prm, x + tx, p + tp, a, s)).max() > 1e-6
+
+
+@pytest.mark.parametrize("inv", ["rel_pos_periodic", "ponita", "polar_periodic", "latitude_periodic", "ball", "ball_lat"])
 def test_latent_gradients_match_finite_differences(inv):
     cfg = small_cfg(inv, D=16, O=1)
     prm = T.to_torch(R.init_params(19, cfg, jitter=0.1), torch.float64)
