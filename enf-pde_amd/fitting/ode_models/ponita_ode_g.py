@@ -1,0 +1,210 @@
+"""PonitaODEGen: the equivariant message-passing network that gives the latents' time derivative, mirroring
+experiments/fitting/ode_models/ponita_ode_g.py (PolynomialFeatures :15-26, ConvBlock :29-49, SepGconv :52-83,
+PonitaGen :86-195, PonitaODEGen :198-258).
+
+Work split (per ODE evaluation, B signals x Z latents):
+  * pair-wise (B Z^2 rows): invariants of (p, p) and their Kronecker powers (element-wise device ops), the kernel-basis
+    MLP (two plain GEMMs: library), and per layer the separable group convolution -- the HIP kernels of
+    csrc/enf_ode.hip (``sep_gconv``: fp32 MFMA, the (B, Z, Z, C) kernel tensor is never materialised), forward and
+    backward;
+  * per-latent (B Z rows): stem, LayerNorm, the widening MLP and the readouts: library GEMMs.
+Everything is differentiable (d/d p, d/d a, d/d weights) so that `ode_loss` (pde_trainer.py:411-500) can be trained
+through the solver.  Parameters: the reference's flax tree ``{'params': {'ponita': {...}}}`` with device tensors.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn.functional as Fnn
+
+from ... import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _SepGconv(torch.autograd.Function):
+    """out[b,r,:] = bias + sum_s a[b,s,:] * (kb[b,r,s,:] @ W)   (SepGconv.__call__, ponita_ode_g.py:63-83)."""
+
+    @staticmethod
+    def forward(ctx, a, kb, W, bias):
+        lib = _lib.load()
+        a, kb, W = a.contiguous(), kb.contiguous(), W.contiguous()
+        B, Z, C = a.shape
+        J = kb.shape[-1]
+        out = torch.empty_like(a)
+        _lib.check(lib.enf_ode_conv_forward(B, Z, J, C, _ptr(a), _ptr(kb), Z * J, J, _ptr(W),
+                                            _ptr(bias.contiguous() if bias is not None else None), _ptr(out), _stream(a.device)))
+        ctx.save_for_backward(a, kb, W)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, kb, W = ctx.saved_tensors
+        g = g.contiguous()
+        B, Z, C = a.shape
+        J = kb.shape[-1]
+        st = _stream(a.device)
+        da = dkb = dW = db = None
+        if ctx.needs_input_grad[0]:       # d a[b,s,:] = sum_r g[b,r,:] * kernel[b,r,s,:]: the same contraction, (r, s) swapped
+            da = torch.empty_like(a)
+            _lib.check(lib.enf_ode_conv_forward(B, Z, J, C, _ptr(g), _ptr(kb), J, Z * J, _ptr(W), _ptr(None), _ptr(da), st))
+        if ctx.needs_input_grad[1]:
+            dkb = torch.empty_like(kb)
+            _lib.check(lib.enf_ode_conv_backward_basis(B, Z, J, C, _ptr(a), _ptr(g), _ptr(W), _ptr(dkb), st))
+        if ctx.needs_input_grad[2]:       # d W = kb^T (g (x) a) over the pair axis: a plain GEMM
+            v = (g[:, :, None, :] * a[:, None, :, :]).reshape(-1, C)
+            dW = kb.reshape(-1, J).t() @ v
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = g.sum((0, 1))
+        return da, dkb, dW, db
+
+
+def sep_gconv(a, kb, W, bias=None):
+    if not a.is_cuda:
+        raise RuntimeError("sep_gconv runs on the HIP kernels of libenf_hip.so only (no CPU path)")
+    if a.dtype != torch.float32 or kb.dtype != torch.float32:
+        raise TypeError("sep_gconv computes in fp32")
+    return _SepGconv.apply(a, kb, W, bias)
+
+
+class PolynomialFeatures:
+    """[x, x(x)x, ...]: degree + 1 Kronecker powers, flattened and concatenated (ponita_ode_g.py:15-26)."""
+
+    def __init__(self, degree):
+        self.degree = degree
+
+    def __call__(self, x):
+        out = [x]
+        for _ in range(self.degree):
+            out.append((out[-1][..., :, None] * x[..., None, :]).flatten(-2))
+        return torch.cat(out, -1)
+
+    def num_features(self, dim):
+        return sum(dim ** k for k in range(1, self.degree + 2))
+
+
+def _gelu(x):
+    return Fnn.gelu(x, approximate="tanh")                 # flax nn.gelu default
+
+
+def _dense(x, p):
+    y = x @ p["kernel"]
+    return y + p["bias"] if "bias" in p else y
+
+
+def _trunc_normal(gen, shape, std, device):
+    t = torch.empty(shape, dtype=torch.float32)
+    torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=gen)
+    return (t * (std / 0.87962566103423978)).to(device)
+
+
+def _lecun(gen, n_in, n_out, device, bias=True):
+    p = {"kernel": _trunc_normal(gen, (n_in, n_out), math.sqrt(1.0 / n_in), device)}      # flax Dense default
+    if bias:
+        p["bias"] = torch.zeros(n_out, device=device)
+    return p
+
+
+class PonitaGen:
+    def __init__(self, num_hidden, num_layers, scalar_num_out, vec_num_out, invariant, basis_dim, degree, widening_factor,
+                 global_pool, kernel_size="global"):
+        assert kernel_size == "global" or kernel_size > 0, "kernel_size must be 'global' or a positive number."   # :100
+        self.num_hidden, self.num_layers, self.scalar_num_out, self.vec_num_out = num_hidden, num_layers, scalar_num_out, vec_num_out
+        self.invariant, self.basis_dim, self.degree, self.widening_factor = invariant, basis_dim, degree, widening_factor
+        self.global_pool, self.kernel_size = global_pool, kernel_size
+        self.poly = PolynomialFeatures(degree)
+
+    # ---- parameters (shapes ponita_ode_g.py:97-134)
+    def init(self, key, latent_dim, device="cuda"):
+        gen = torch.Generator().manual_seed(int(key))
+        inv, H, J = self.invariant, self.num_hidden, self.basis_dim
+        P = {"kernel_basis": {"layers_1": _lecun(gen, self.poly.num_features(inv.dim), H, device),
+                              "layers_3": _lecun(gen, H, J, device)},
+             "a_stem": _lecun(gen, latent_dim, H, device, bias=False)}
+        lim = math.sqrt(2.0 / (J + H) * J)                                                # chang_xavier_uniform, :9-13
+        for i in range(self.num_layers):
+            P[f"interaction_layers_{i}"] = {
+                "conv": {"kernel": {"kernel": ((torch.rand((J, H), generator=gen) * 2 - 1) * lim).to(device)},
+                         "bias": torch.zeros(H, device=device)},
+                "norm": {"scale": torch.ones(H, device=device), "bias": torch.zeros(H, device=device)},
+                "linear_1": _lecun(gen, H, self.widening_factor * H, device),
+                "linear_2": _lecun(gen, self.widening_factor * H, H, device)}
+        ro = lambda n_in, n_out: {"kernel": _trunc_normal(gen, (n_in, n_out), math.sqrt(1e-6 / n_in), device)}   # :124
+        P["readout_scalar"] = {"layers_0": ro(H, self.scalar_num_out)}
+        if self.vec_num_out > 0:
+            P["readout_vec_rel"] = ro(inv.dim + H, self.vec_num_out)
+            if inv.num_z_ori_dims > 0:
+                P["readout_vec_ori"] = ro(inv.dim + H, self.vec_num_out)
+        return P
+
+    def __call__(self, P, latent):
+        p, a, _ = latent
+        inv = self.invariant
+        zp = inv.num_z_pos_dims
+        if inv.num_z_ori_dims > 0:                                                        # :152-155
+            p = torch.cat((p[..., :zp], torch.cos(p[..., zp:]), torch.sin(p[..., zp:])), -1)
+        invariants = inv(p, p)                                                            # (B, Z, Z, I)
+        kb = _gelu(_dense(_gelu(_dense(self.poly(invariants), P["kernel_basis"]["layers_1"])), P["kernel_basis"]["layers_3"]))
+        if self.kernel_size != "global":                                                  # :162-164
+            kb = kb * torch.exp(-torch.linalg.norm(p[:, :, None, :] - p[:, None, :, :], dim=-1) / self.kernel_size)[..., None]
+        a = _dense(a, P["a_stem"])
+        for i in range(self.num_layers):                                                  # ConvBlock, :42-49
+            L = P[f"interaction_layers_{i}"]
+            x = sep_gconv(a, kb, L["conv"]["kernel"]["kernel"], L["conv"]["bias"])
+            x = Fnn.layer_norm(x, (x.shape[-1],), L["norm"]["scale"], L["norm"]["bias"], 1e-6)
+            a = _dense(_gelu(_dense(x, L["linear_1"])), L["linear_2"])
+        scalar_out = _dense(a, P["readout_scalar"]["layers_0"])
+        vec_out = None
+        if self.vec_num_out > 0:                                                          # :176-193
+            rel_pos = p[:, :, None, :zp] - p[:, None, :, :zp]
+            # Dense([invariants | a_s]) = invariants @ W[:I] + (a @ W[I:]) of the sender, without the (B, Z, Z, I + H) concat
+            I = invariants.shape[-1]
+
+            def readout(Wk):
+                return invariants @ Wk[:I] + (a @ Wk[I:])[:, None, :, :]
+            vec_out = (readout(P["readout_vec_rel"]["kernel"]) * rel_pos).mean(-2)
+            if inv.num_z_ori_dims > 0:
+                vec_out = vec_out + (readout(P["readout_vec_ori"]["kernel"]) * p[:, None, :, zp:]).mean(-2)
+        if self.global_pool:
+            scalar_out = scalar_out.mean(1)
+            vec_out = vec_out.mean(1) if vec_out is not None else None
+        return scalar_out, vec_out
+
+
+class PonitaODEGen:
+    """``init(key, latents) -> params``, ``apply(params, latents) -> (dp/dt, da/dt, dwindow/dt)`` (flax calling style)."""
+
+    def __init__(self, num_hidden, num_layers, scalar_num_out, vec_num_out, invariant, basis_dim, degree, widening_factor,
+                 global_pool, kernel_size="global"):
+        self.invariant = invariant
+        self.scalar_num_out = scalar_num_out
+        n_sc = scalar_num_out + 1 if invariant.num_z_ori_dims > 0 else scalar_num_out          # :212-217 (angle update)
+        self.ponita = PonitaGen(num_hidden, num_layers, n_sc, vec_num_out, invariant, basis_dim, degree, widening_factor,
+                                global_pool, kernel_size)
+
+    def init(self, key, latents, device=None):
+        p, a, _ = latents
+        return {"params": {"ponita": self.ponita.init(key, a.shape[-1], device or a.device)}}
+
+    def load_params(self, tree, device="cuda"):
+        """A reference parameter tree (numpy leaves, flax names) -> device tensors."""
+        conv = lambda t: {k: conv(v) for k, v in t.items()} if isinstance(t, dict) else \
+            torch.as_tensor(t, dtype=torch.float32).to(device).contiguous()
+        return conv(tree)
+
+    def apply(self, params, latents):
+        p, a, window = latents
+        scalar, vec = self.ponita(params["params"]["ponita"], (p, a - 1, window))            # a has mean 1 (:233)
+        if self.invariant.num_z_ori_dims > 0:
+            da, dp = scalar[..., :-1], torch.cat([vec, scalar[..., -1:]], -1)
+        else:
+            da, dp = scalar, vec
+        return dp, da, (torch.zeros_like(window) if window is not None else None)

@@ -198,6 +198,21 @@ int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const
 int enf_mse_value_grad(const float* out, const float* target, size_t n, float grad_scale, float* dout, float* loss,
                        void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Latent ODE (experiments/fitting/ode_models/ponita_ode_g.py): the separable group convolution of a ConvBlock,
+ * SepGconv.__call__ (:63-83), over the fully connected latent set of every signal:
+ *     out[b,r,:] = bias + sum_s a[b,s,:] * (kb[b,r,s,:] @ W)        a (B,Z,C), kb (B,Z,Z,J), W (J,C), bias (C) or NULL
+ * fused: the (B,Z,Z,C) `kernel` tensor the reference materialises (:72) never exists; the J -> C product runs as fp32
+ * MFMA tiles consumed in registers.  kb element (b,r,s,j) is read at b*Z*Z*J + r*kb_stride_r + s*kb_stride_s + j, so
+ * the same entry point gives the gradient w.r.t. the senders:  d a = conv(g, kb with the (r,s) strides swapped, W, NULL).
+ * enf_ode_conv_backward_basis:  d kb[b,r,s,:] = W (g[b,r,:] * a[b,s,:])   (B,Z,Z,J).
+ * d W = kb^T (g (x) a) over the pair axis is a plain GEMM, left to the caller's BLAS; d bias = sum_{b,r} g.
+ * J, C in {16, 32, 64, 128}; all buffers fp32, contiguous, 16-byte aligned. */
+int enf_ode_conv_forward(int B, int Z, int J, int C, const float* a, const float* kb, int64_t kb_stride_r,
+                         int64_t kb_stride_s, const float* W, const float* bias, float* out, void* stream);
+int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const float* a, const float* g, const float* W, float* dkb,
+                                void* stream);
+
 /* Forward pair-kernel variant: -1 = choose by problem size (default), 0 = latent-split, 1 = z-fold
  * (DESIGN.md 5).  Also settable with ENF_ZFOLD=0/1 in the environment.  Affects enf_workspace_bytes /
  * enf_pair_scratch_bytes: size buffers after setting it.  Process-wide; meant for tests and benchmarks. */

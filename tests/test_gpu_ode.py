@@ -1,0 +1,170 @@
+"""Latent ODE on the GPU: the fused separable group convolution (csrc/enf_ode.hip) against a plain
+PyTorch reference of the same op, and PonitaODEGen / MLPODE / the solvers against the oracle (fp64), values and
+gradients w.r.t. latents and weights."""
+import numpy as np
+import pytest
+import torch
+from types import SimpleNamespace as NS
+
+from oracle import enf_ref_torch as T
+from oracle import ode_ref_np as O
+from oracle import ode_ref_torch as OT
+from tests.test_ode_oracle import ode_cfg, ode_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("B,Z,J,C,bias", [(3, 7, 16, 16, True), (2, 16, 64, 128, True), (2, 64, 64, 128, False),
+                                          (1, 25, 128, 32, True), (4, 9, 32, 64, True), (2, 33, 128, 128, True)])
+def test_sep_gconv_matches_einsum(cuda, B, Z, J, C, bias):
+    from enf_pde_amd.fitting.ode_models import sep_gconv
+    g = torch.Generator().manual_seed(Z + J)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    a, kb, W, b_, w = mk(B, Z, C), mk(B, Z, Z, J), mk(J, C) / J ** 0.5, mk(C), mk(B, Z, C)
+    ref_in = [t.clone().requires_grad_(True) for t in (a, kb, W, b_)]
+    ref = torch.einsum("bsc,brsc->brc", ref_in[0], ref_in[1] @ ref_in[2]) + (ref_in[3] if bias else 0)   # ponita_ode_g.py:72-82
+    (ref * w).sum().backward()
+    dev_in = [t.to(cuda, torch.float32).requires_grad_(True) for t in (a, kb, W, b_)]
+    out = sep_gconv(dev_in[0], dev_in[1], dev_in[2], dev_in[3] if bias else None)
+    (out * w.to(cuda, torch.float32)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(out.detach().cpu().double().numpy(), ref.detach().numpy()) < 1e-5
+    for i, name in enumerate(["a", "kb", "W", "bias"][:4 if bias else 3]):
+        assert rel(dev_in[i].grad.cpu().double().numpy(), ref_in[i].grad.numpy()) < 2e-5, name
+
+
+def test_sep_gconv_rejects_unsupported(cuda):
+    from enf_pde_amd.fitting.ode_models import sep_gconv
+    z = lambda *s: torch.zeros(*s, device=cuda)
+    with pytest.raises(NotImplementedError):
+        sep_gconv(z(1, 4, 24), z(1, 4, 4, 16), z(16, 24))          # C not in {16, 32, 64, 128}
+    with pytest.raises(RuntimeError):
+        sep_gconv(torch.zeros(1, 4, 16), torch.zeros(1, 4, 4, 16), torch.zeros(16, 16))    # no CPU path
+
+
+def _flat(tree, prefix=""):
+    for k in sorted(tree):
+        if isinstance(tree[k], dict):
+            yield from _flat(tree[k], prefix + k + "/")
+        else:
+            yield prefix + k, tree[k]
+
+
+def _model(cfg, latent_dim):
+    from enf_pde_amd.enf.steerable_attention.invariant import get_sa_invariant
+    from enf_pde_amd.fitting.ode_models import PonitaODEGen
+    inv = get_sa_invariant(NS(invariant_type=cfg["invariant"], num_in=cfg["num_in"]))
+    return PonitaODEGen(num_hidden=cfg["num_hidden"], num_layers=cfg["num_layers"], scalar_num_out=latent_dim, vec_num_out=1,
+                        invariant=inv, basis_dim=cfg["basis_dim"], degree=cfg["degree"], widening_factor=cfg["widening_factor"],
+                        global_pool=False, kernel_size=cfg["kernel_size"])
+
+
+@pytest.mark.parametrize("inv,Z,C,hid,basis,ks", [("rel_pos_periodic", 16, 16, 128, 64, "global"),      # config_navier_stokes.yaml
+                                                  ("ponita", 9, 32, 128, 128, 0.2),                      # config_cahn_hilliard.yaml
+                                                  ("polar_periodic", 18, 4, 32, 32, "global"),           # config_diff_sphere.yaml
+                                                  ("latitude_periodic", 8, 32, 128, 64, "global"),       # config_shallow_water.yaml
+                                                  ("ball", 25, 32, 128, 64, "global"),                   # config_ihc.yaml
+                                                  ("rel_pos", 5, 8, 16, 16, "global")])
+def test_ponita_ode_matches_oracle(cuda, inv, Z, C, hid, basis, ks):
+    cfg = ode_cfg(inv, num_hidden=hid, basis_dim=basis, num_layers=3, kernel_size=ks)
+    prm = O.init_ponita_ode(Z + C, cfg, latent_dim=C, jitter=0.1, readout_scale=1.0)
+    lat = ode_inputs(cfg, 2, Z, C, Z)
+    rng = np.random.default_rng(3)
+    wp, wa = rng.standard_normal(lat[0].shape), rng.standard_normal(lat[1].shape)
+    # oracle, fp64, autograd
+    rp = T.to_torch(prm, torch.float64, requires_grad=True)
+    rl = [torch.tensor(v, requires_grad=True) for v in lat[:2]] + [torch.tensor(lat[2])]
+    odp, oda, odw = OT.ponita_ode(rp, cfg, tuple(rl))
+    ((odp * torch.tensor(wp)).sum() + (oda * torch.tensor(wa)).sum()).backward()
+    # product
+    model = _model(cfg, C)
+    P = model.load_params(prm, device=cuda)
+    leaves = dict(_flat(P))
+    for v in leaves.values():
+        v.requires_grad_(True)
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    p, a, w = t(lat[0], True), t(lat[1], True), t(lat[2])
+    dp, da, dw = model.apply(P, (p, a, w))
+    ((dp * t(wp)).sum() + (da * t(wa)).sum()).backward()
+    torch.cuda.synchronize()
+    n = lambda v: v.detach().cpu().double().numpy()
+    assert dp.shape == p.shape and da.shape == a.shape and not n(dw).any()
+    assert rel(n(dp), odp.detach().numpy()) < 2e-4 and rel(n(da), oda.detach().numpy()) < 2e-4
+    assert rel(n(p.grad), rl[0].grad.numpy()) < 1e-3 and rel(n(a.grad), rl[1].grad.numpy()) < 1e-3
+    ref_leaves = dict(_flat(rp))
+    assert set(ref_leaves) == set(leaves)
+    for k, v in leaves.items():
+        assert rel(n(v.grad), ref_leaves[k].grad.numpy()) < 2e-3, k
+
+
+def test_init_shapes_and_flax_names(cuda):
+    cfg = ode_cfg("ponita", num_hidden=32, basis_dim=16, num_layers=3)
+    model = _model(cfg, 8)
+    lat = tuple(torch.tensor(v, dtype=torch.float32, device=cuda) for v in ode_inputs(cfg, 1, 4, 8, 0))
+    P = model.init(0, lat)
+    ref = O.init_ponita_ode(0, cfg, latent_dim=8)
+    got, want = dict(_flat(P)), dict(_flat(ref))
+    assert {k: tuple(v.shape) for k, v in got.items()} == {k: tuple(v.shape) for k, v in want.items()}
+    k1 = got["params/ponita/kernel_basis/layers_1/kernel"]
+    assert abs(float(k1.std()) - (1 / 120) ** 0.5) < 0.15 * (1 / 120) ** 0.5         # lecun_normal over 120 polynomial features
+    assert float(got["params/ponita/readout_scalar/layers_0/kernel"].abs().max()) < 1e-2   # variance_scaling(1e-6)
+    dp, da, dw = model.apply(P, lat)                                                  # near-zero derivative at init
+    assert dp.shape == (1, 4, 3) and da.shape == (1, 4, 8) and float(da.abs().max()) < 1e-1
+
+
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_rollout_matches_oracle(cuda, method):
+    from enf_pde_amd.fitting.trainers.trainer_utils import solve_latent_ode
+    cfg = ode_cfg("rel_pos_periodic", num_hidden=32, basis_dim=16, num_layers=2)
+    prm = O.init_ponita_ode(5, cfg, latent_dim=8, jitter=0.1, readout_scale=0.05)
+    lat = ode_inputs(cfg, 2, 6, 8, 6)
+    ref = O.solve_latent_ode(lambda z, t: O.ponita_ode(prm, cfg, z), lat, 0, 4, 1, method=method)
+    model = _model(cfg, 8)
+    P = model.load_params(prm, device=cuda)
+    dl = tuple(torch.tensor(v, dtype=torch.float32, device=cuda) for v in lat)
+    with torch.no_grad():
+        got = solve_latent_ode(lambda z, t: model.apply(P, z), dl, 0, 4, 1, method=method)
+    for g, r in zip(got, ref):
+        assert tuple(g.shape) == r.shape and r.shape[1] == 5
+        assert rel(g.cpu().double().numpy(), r) < 2e-4
+    assert np.abs(ref[1][:, -1] - ref[1][:, 0]).max() > 1e-3          # the latents do move
+
+
+def test_rollout_gradient_reaches_the_ode_weights(cuda):
+    """ode_loss (pde_trainer.py:411-500) differentiates a roll-out w.r.t. the ODE parameters."""
+    from enf_pde_amd.fitting.trainers.trainer_utils import solve_latent_ode
+    cfg = ode_cfg("ponita", num_hidden=16, basis_dim=16, num_layers=1)
+    prm = O.init_ponita_ode(7, cfg, latent_dim=4, readout_scale=0.05)
+    lat = ode_inputs(cfg, 1, 4, 4, 8)
+    rp = T.to_torch(prm, torch.float64, requires_grad=True)
+    rt = OT.solve_latent_ode(lambda z, t: OT.ponita_ode(rp, cfg, z), tuple(torch.tensor(v) for v in lat), 0, 3, 1, method="euler")
+    (rt[0] ** 2).sum().add((rt[1] ** 2).sum()).backward()
+    model = _model(cfg, 4)
+    P = model.load_params(prm, device=cuda)
+    leaves = dict(_flat(P))
+    for v in leaves.values():
+        v.requires_grad_(True)
+    dl = tuple(torch.tensor(v, dtype=torch.float32, device=cuda) for v in lat)
+    gt = solve_latent_ode(lambda z, t: model.apply(P, z), dl, 0, 3, 1, method="euler")
+    (gt[0] ** 2).sum().add((gt[1] ** 2).sum()).backward()
+    ref_leaves = dict(_flat(rp))
+    for k, v in leaves.items():
+        assert rel(v.grad.cpu().double().numpy(), ref_leaves[k].grad.numpy()) < 2e-3, k
+
+
+def test_mlp_ode_matches_oracle(cuda):
+    from enf_pde_amd.fitting.ode_models import MLPODE
+    prm = O.init_mlp_ode(13, 32, 2, 8)
+    rng = np.random.default_rng(14)
+    lat = (rng.uniform(-1, 1, (2, 6, 2)), 1 + 0.2 * rng.standard_normal((2, 6, 8)), np.ones((2, 6, 1)))
+    rp, ra, _ = O.mlp_ode(prm, lat)
+    m = MLPODE(num_hidden=32, num_layers=3, scalar_num_out=8, vec_num_out=1)
+    dl = tuple(torch.tensor(v, dtype=torch.float32, device=cuda) for v in lat)
+    dp, da, dw = m.apply(m.load_params(prm, device=cuda), dl)
+    assert rel(dp.cpu().double().numpy(), rp) < 1e-5 and rel(da.cpu().double().numpy(), ra) < 1e-5 and not dw.any()
+    shapes = {k: tuple(v.shape) for k, v in _flat(m.init(0, dl))}
+    assert shapes == {k: tuple(v.shape) for k, v in _flat(prm)}
