@@ -1,4 +1,5 @@
-"""Outer (meta) step of the ENF trainer -- the nef phase of experiments/fitting/trainers/pde_trainer.py.
+"""Outer (meta) steps of the ENF trainer, mirroring experiments/fitting/trainers/pde_trainer.py: the nef phase
+(nef_train_step), the latent-ODE phase (ode_loss, ode_train_step, dual_train_step) and val_step.
 
 Reference:  recon_loss, grads = jax.value_and_grad(self.enf_loss)(params, state, trajectory)   (pde_trainer.py:255)
 where enf_loss = the loss of the LAST inner step after S meta-SGD steps from the shared latent initialisation
@@ -33,12 +34,29 @@ from types import SimpleNamespace
 
 import torch
 
-from ..inner_loop import _pose, make_masks
+from ..inner_loop import _pose, make_masks, inner_loop, decode
+from .trainer_utils.solvers import solve_latent_ode
 from ..optim import Adam, AdamW, clip_by_global_norm
 from ..parallel import allreduce_mean_
 from ...enf.models import TENSOR_PATHS, _get, _set
 
 LATENT_KEYS = ("p_pos", "p_ori", "a", "gaussian_window")
+
+
+def _leaves(tree):
+    """Leaves of a nested parameter dict in a fixed (sorted-key) order."""
+    out = []
+    for k in sorted(tree):
+        out += _leaves(tree[k]) if isinstance(tree[k], dict) else [tree[k]]
+    return out
+
+
+def _unflatten(tree, leaves):
+    it = iter(leaves)
+
+    def build(t):
+        return {k: (build(t[k]) if isinstance(t[k], dict) else next(it)) for k in sorted(t)}
+    return build(tree)
 
 
 def _tree_from_tensors(tensors):
@@ -75,11 +93,14 @@ def _full_grads(nef, weights, coords, img, masks, s, lat, keys):
 
 
 def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaussian_window=False,
-                   second_order="fd", fd_step=2e-2, noise_pos=0.0, generator=None):
+                   second_order="fd", fd_step=2e-2, noise_pos=0.0, generator=None, terminal=None):
     """Value and gradient of the last-inner-step loss w.r.t. (nef weights, meta-init latents, inner lrs).
 
     Returns (loss, grads) with grads = {'nef': [46 tensors in ENF_W_* order], 'autodecoder': {key: (1,Z,.)},
     'meta_sgd_lrs': {key: like lrs[key]}}.
+
+    ``terminal(weights, lat, keys) -> (loss, d loss/d weights, {key: d loss/d lat[key]})`` replaces the objective on
+    the fitted latents (default: the reconstruction loss on the last mask); dual_train_step passes the roll-out loss.
     """
     if second_order not in ("fd", "none"):
         raise ValueError("second_order must be 'fd' or 'none'")
@@ -104,7 +125,10 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
         gs.append(g)
         lat = {k: (lat[k] - lrs[k] * g[k]).detach() for k in lat}                                       # pde_trainer.py:215-219
     # ---- last step: value, d/d theta, lambda_S
-    loss, g_theta, lam = _full_grads(nef, weights, coords, img, masks, S, lat, keys)
+    if terminal is None:
+        loss, g_theta, lam = _full_grads(nef, weights, coords, img, masks, S, lat, keys)
+    else:
+        loss, g_theta, lam = terminal(weights, lat, keys)
     lam = {k: lam.get(k, torch.zeros_like(lat[k])) for k in lat}
     g_alpha = {k: torch.zeros_like(lrs[k]) for k in lrs}
     # ---- adjoint sweep
@@ -137,6 +161,7 @@ class TrainState:
     nef_opt_state: dict
     autodecoder_opt_state: dict
     meta_sgd_opt_state: dict
+    ode_opt_state: dict = None
     step: int = 0
     rng: torch.Generator = field(default_factory=lambda: torch.Generator().manual_seed(0))
 
@@ -146,19 +171,21 @@ class MetaSGDPDETrainer:
 
     ``config`` carries the reference's field names: optimizer.learning_rate_enf, optimizer.learning_rate_codes,
     meta.learning_rate_meta_sgd, meta.num_inner_steps, meta.inner_learning_rate_{p,a,window},
-    meta.noise_pos_inner_loop, nef.optimize_gaussian_window, training.max_num_sampled_points.
-    The latent-ODE phase (ode_train_step, dual_train_step) is outside this build's scope.
+    meta.noise_pos_inner_loop, nef.optimize_gaussian_window, training.max_num_sampled_points; with an ``ode_model``
+    also optimizer.learning_rate_ode, node.dt, node.method, dataset.traj_len_train, dataset.traj_len_out_horizon.
     """
 
-    def __init__(self, config, nef, outer_autodecoder, coords, seed=0, second_order="fd", fd_step=2e-2):
+    def __init__(self, config, nef, outer_autodecoder, coords, seed=0, second_order="fd", fd_step=2e-2, ode_model=None):
         self.config, self.nef, self.outer_autodecoder, self.coords, self.seed = config, nef, outer_autodecoder, coords, seed
         self.second_order, self.fd_step = second_order, fd_step
+        self.ode_model = ode_model
         o, m = config.optimizer, config.meta
         self.nef_opt = AdamW(o.learning_rate_enf)                              # after clip_by_global_norm(1.0)
         self.autodecoder_opt = Adam(o.learning_rate_codes)
         self.meta_sgd_opt = Adam(m.learning_rate_meta_sgd)
+        self.ode_opt = Adam(getattr(o, "learning_rate_ode", 1e-3)) if ode_model is not None else None   # pde_trainer.py:66
 
-    def init_train_state(self, nef_params=None):
+    def init_train_state(self, nef_params=None, ode_params=None):
         cfg, dev = self.config, self.coords.device
         g = torch.Generator().manual_seed(self.seed)
         ad = self.outer_autodecoder.init(g, device=dev)                          # pde_trainer.py:79-81
@@ -171,11 +198,18 @@ class MetaSGDPDETrainer:
         if nef_params is None:
             nef_params = self.nef.init(g, device=dev)                            # pde_trainer.py:99-102
         params = {"nef": nef_params, "autodecoder": ad, "meta_sgd_lrs": lrs}
+        ode_opt_state = None
+        if self.ode_model is not None:                                           # pde_trainer.py:104-105
+            P = ad["params"]
+            p0 = torch.cat((P["p_pos"], P["p_ori"]), -1) if self.outer_autodecoder.num_ori_dims > 0 else P["p_pos"]
+            params["ode_params"] = ode_params if ode_params is not None else \
+                self.ode_model.init(self.seed + 1, (p0, P["a"], P.get("gaussian_window")), device=dev)
+            ode_opt_state = self.ode_opt.init(_leaves(params["ode_params"]))
         return TrainState(params=params,
                           nef_opt_state=self.nef_opt.init(self.nef.param_tensors(nef_params)),
                           autodecoder_opt_state=self.autodecoder_opt.init(list(ad["params"].values())),
                           meta_sgd_opt_state=self.meta_sgd_opt.init(list(lrs.values())),
-                          step=0, rng=g)
+                          ode_opt_state=ode_opt_state, step=0, rng=g)
 
     def _latents0(self, state):
         P = state.params["autodecoder"]["params"]
@@ -218,7 +252,138 @@ class MetaSGDPDETrainer:
         new_lrs, lr_state = self.meta_sgd_opt.update([grads["meta_sgd_lrs"][k] for k in lr_keys], state.meta_sgd_opt_state,
                                                      [lrs[k] for k in lr_keys])
         lrs = {k: v.clamp(1e-6, 10.0) for k, v in zip(lr_keys, new_lrs)}
-        new_state = TrainState(params={"nef": nef_params, "autodecoder": ad, "meta_sgd_lrs": lrs},
-                               nef_opt_state=nef_opt_state, autodecoder_opt_state=ad_state, meta_sgd_opt_state=lr_state,
-                               step=state.step + 1, rng=state.rng)
+        params = dict(state.params, nef=nef_params, autodecoder=ad, meta_sgd_lrs=lrs)     # ode_params carried over
+        new_state = TrainState(params=params, nef_opt_state=nef_opt_state, autodecoder_opt_state=ad_state,
+                               meta_sgd_opt_state=lr_state, ode_opt_state=state.ode_opt_state, step=state.step + 1, rng=state.rng)
         return loss, new_state
+
+    # ------------------------------------------------------------------ latent-ODE phase (pde_trainer.py:290-500)
+    def _fit_initial_latents(self, state, initial_state, masks=None, initial_state_dp=0.0):
+        """inner_loop on the first frame of every trajectory (pde_trainer.py:424-427): fitted latents, leading dim B."""
+        cfg = self.config
+        img = initial_state.reshape(initial_state.shape[0], -1, initial_state.shape[-1])
+        coords = self.coords
+        if initial_state_dp > 0:                                                  # pde_trainer.py:139-145
+            keep = torch.randperm(coords.shape[0], generator=state.rng)[:int(coords.shape[0] * initial_state_dp)].to(coords.device)
+            coords, img = coords[keep], img[:, keep]
+        if masks is None:
+            masks = make_masks(coords.shape[0], cfg.training.max_num_sampled_points, cfg.meta.num_inner_steps,
+                               generator=state.rng, device=coords.device)
+        return coords, img, masks
+
+    def rollout(self, ode_params, lat, num_frames):
+        """Latents of ``num_frames`` frames from the fitted ones: (B, T, Z, .) each (pde_trainer.py:432-441)."""
+        cfg = self.config
+        n_ori = self.nef.cross_attn_invariant.num_z_ori_dims
+        z0 = (_pose(lat, n_ori), lat["a"], lat.get("gaussian_window"))
+        return solve_latent_ode(lambda z, t: self.ode_model.apply(ode_params, z), z0, 0, num_frames - 1, cfg.node.dt,
+                                method=cfg.node.method)
+
+    def ode_loss(self, nef_params, ode_params, lat, trajectory, point_masks=None, generator=None):
+        """pde_trainer.py:411-481 from the fitted latents on: roll the latents out over the training frames, decode every
+        frame (at ``max_num_sampled_points`` random grid points per frame when the grid is larger) and compare.
+        ``trajectory`` (B, T, *grid, O);  ``point_masks`` (T, n_s) long, or None to draw them."""
+        cfg = self.config
+        B, T = trajectory.shape[:2]
+        sol = self.rollout(ode_params, lat, T)
+        p_fl, a_fl, w_fl = (None if v is None else v.reshape(B * T, *v.shape[2:]) for v in sol)
+        traj = trajectory.reshape(B, T, -1, trajectory.shape[-1])
+        N, n_s = self.coords.shape[0], cfg.training.max_num_sampled_points
+        if n_s < N:                                                               # pde_trainer.py:446-471
+            if point_masks is None:
+                point_masks = torch.stack([torch.randperm(N, generator=generator)[:n_s] for _ in range(T)]).to(self.coords.device)
+            xs = self.coords[point_masks][None].expand(B, -1, -1, -1).reshape(B * T, n_s, -1)
+            ys = torch.gather(traj, 2, point_masks[None, :, :, None].expand(B, -1, -1, traj.shape[-1])).reshape(B * T, n_s, -1)
+        else:
+            xs = self.coords[None].expand(B * T, -1, -1)
+            ys = traj.reshape(B * T, N, -1)
+        recon = self.nef.apply(nef_params, xs, p_fl, a_fl, w_fl)
+        return ((recon - ys) ** 2).mean()
+
+    def _fitted(self, state, trajectory, masks):
+        coords, img, masks = self._fit_initial_latents(state, trajectory[:, 0], masks)
+        cfg = self.config
+        _, lat = inner_loop(self.nef, state.params["nef"], self._latents0(state), state.params["meta_sgd_lrs"], coords, img, masks,
+                            optimize_gaussian_window=getattr(cfg.nef, "optimize_gaussian_window", False),
+                            noise_pos=getattr(cfg.meta, "noise_pos_inner_loop", 0.0), generator=state.rng)
+        return {k: v.detach() for k, v in lat.items()}
+
+    def ode_train_step(self, state, trajectory, masks=None, point_masks=None):
+        """pde_trainer.py:290-318: one Adam step on the ODE parameters only.  The fitted latents do not depend on them, so
+        the inner loop runs without a graph; the gradient flows decoder -> (HIP latent backward) -> solver -> ODE model."""
+        cfg = self.config
+        trajectory = trajectory[:, :cfg.dataset.traj_len_train]                  # pde_trainer.py:421-422
+        lat = self._fitted(state, trajectory, masks)
+        leaves = [t.detach().requires_grad_(True) for t in _leaves(state.params["ode_params"])]
+        ode_params = _unflatten(state.params["ode_params"], leaves)
+        loss = self.ode_loss(state.params["nef"], ode_params, lat, trajectory, point_masks, state.rng)
+        grads = list(torch.autograd.grad(loss, leaves, allow_unused=True))
+        grads = [torch.zeros_like(t) if g is None else g for t, g in zip(leaves, grads)]
+        flat = grads + [loss.detach().reshape(1)]
+        allreduce_mean_(flat)
+        new_leaves, ode_opt_state = self.ode_opt.update(grads, state.ode_opt_state, [t.detach() for t in leaves])
+        params = dict(state.params, ode_params=_unflatten(state.params["ode_params"], new_leaves))
+        return flat[-1][0], TrainState(params=params, nef_opt_state=state.nef_opt_state,
+                                       autodecoder_opt_state=state.autodecoder_opt_state, meta_sgd_opt_state=state.meta_sgd_opt_state,
+                                       ode_opt_state=ode_opt_state, step=state.step + 1, rng=state.rng)
+
+    def dual_train_step(self, state, trajectory, masks=None, point_masks=None):
+        """pde_trainer.py:320-358: the roll-out loss trains the nef weights (clip + AdamW), the inner learning rates (Adam,
+        clipped) and the ODE parameters (Adam); the latent initialisation is left alone.  The nef / learning-rate
+        gradients include the path through the inner loop (the same adjoint recursion as nef_train_step, started from
+        d loss / d fitted latents of the roll-out)."""
+        cfg = self.config
+        trajectory = trajectory[:, :cfg.dataset.traj_len_train]
+        coords, img, masks = self._fit_initial_latents(state, trajectory[:, 0], masks)
+        leaves = [t.detach().requires_grad_(True) for t in _leaves(state.params["ode_params"])]
+        ode_params = _unflatten(state.params["ode_params"], leaves)
+        if point_masks is None and cfg.training.max_num_sampled_points < self.coords.shape[0]:
+            point_masks = torch.stack([torch.randperm(self.coords.shape[0], generator=state.rng)[:cfg.training.max_num_sampled_points]
+                                       for _ in range(trajectory.shape[1])]).to(self.coords.device)
+        side = {}
+
+        def terminal(weights, lat, keys):
+            w = [t.detach().requires_grad_(True) for t in weights]
+            lv = {k: lat[k].detach().requires_grad_(True) for k in lat}
+            loss = self.ode_loss(_tree_from_tensors(w), ode_params, lv, trajectory, point_masks)
+            g = torch.autograd.grad(loss, w + [lv[k] for k in keys] + leaves, allow_unused=True)
+            z = lambda t, gi: torch.zeros_like(t) if gi is None else gi
+            side["ode"] = [z(t, gi) for t, gi in zip(leaves, g[len(w) + len(keys):])]
+            return loss.detach(), [z(t, gi) for t, gi in zip(w, g[:len(w)])], \
+                {k: z(lat[k], gi) for k, gi in zip(keys, g[len(w):len(w) + len(keys)])}
+
+        lrs = state.params["meta_sgd_lrs"]
+        loss, grads = meta_gradients(self.nef, state.params["nef"], self._latents0(state), lrs, coords, img, masks,
+                                     optimize_gaussian_window=getattr(cfg.nef, "optimize_gaussian_window", False),
+                                     second_order=self.second_order, fd_step=self.fd_step,
+                                     noise_pos=getattr(cfg.meta, "noise_pos_inner_loop", 0.0), generator=state.rng, terminal=terminal)
+        lr_keys = list(lrs.keys())
+        flat = grads["nef"] + [grads["meta_sgd_lrs"][k] for k in lr_keys] + side["ode"] + [loss.reshape(1)]
+        allreduce_mean_(flat)
+        weights = self.nef.param_tensors(state.params["nef"])
+        new_w, nef_opt_state = self.nef_opt.update(clip_by_global_norm(grads["nef"], 1.0), state.nef_opt_state, weights)
+        new_lrs, lr_state = self.meta_sgd_opt.update([grads["meta_sgd_lrs"][k] for k in lr_keys], state.meta_sgd_opt_state,
+                                                     [lrs[k] for k in lr_keys])
+        new_leaves, ode_opt_state = self.ode_opt.update(side["ode"], state.ode_opt_state, [t.detach() for t in leaves])
+        params = dict(state.params, nef=_tree_from_tensors(new_w), meta_sgd_lrs={k: v.clamp(1e-6, 10.0) for k, v in zip(lr_keys, new_lrs)},
+                      ode_params=_unflatten(state.params["ode_params"], new_leaves))
+        return flat[-1][0], TrainState(params=params, nef_opt_state=nef_opt_state, autodecoder_opt_state=state.autodecoder_opt_state,
+                                       meta_sgd_opt_state=lr_state, ode_opt_state=ode_opt_state, step=state.step + 1, rng=state.rng)
+
+    @torch.no_grad()
+    def val_step(self, state, trajectory, initial_state_dp=0.0, masks=None):
+        """pde_trainer.py:360-409: fit the first frame, roll out over train + out-of-horizon frames, decode the full grid;
+        returns (mse over the training horizon, mse beyond it)."""
+        cfg = self.config
+        T_in = cfg.dataset.traj_len_train
+        trajectory = trajectory[:, :T_in + cfg.dataset.traj_len_out_horizon]
+        B, T = trajectory.shape[:2]
+        coords, img, masks = self._fit_initial_latents(state, trajectory[:, 0], masks, initial_state_dp)
+        with torch.enable_grad():
+            _, lat = inner_loop(self.nef, state.params["nef"], self._latents0(state), state.params["meta_sgd_lrs"], coords, img, masks,
+                                optimize_gaussian_window=getattr(cfg.nef, "optimize_gaussian_window", False))
+        sol = self.rollout(state.params["ode_params"], {k: v.detach() for k, v in lat.items()}, T)
+        p_fl, a_fl, w_fl = (None if v is None else v.reshape(B * T, *v.shape[2:]) for v in sol)
+        recon = decode(self.nef, state.params["nef"], self.coords, p_fl, a_fl, w_fl).reshape(trajectory.shape)
+        err = (recon - trajectory) ** 2
+        return err[:, :T_in].mean(), (err[:, T_in:].mean() if T > T_in else err.new_zeros(()))
