@@ -28,6 +28,41 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+SPLIT_K = 4096      # rows per slice of the pair axis in a weight-gradient GEMM X^T G: (K x P)(P x N) has only K N / tile^2
+                    # output tiles, so the library GEMM runs batched over slices of P and the slices are summed
+
+
+def _xt_dot(X, G):
+    """X^T @ G for X (P, K), G (P, N) with P >> K, N: split-K over the pair axis."""
+    P = X.shape[0]
+    n = P // SPLIT_K
+    if n < 2:
+        return X.t() @ G
+    out = torch.bmm(X[:n * SPLIT_K].view(n, SPLIT_K, -1).transpose(1, 2), G[:n * SPLIT_K].view(n, SPLIT_K, -1)).sum(0)
+    if n * SPLIT_K < P:
+        out = out + X[n * SPLIT_K:].t() @ G[n * SPLIT_K:]
+    return out
+
+
+class _PairDense(torch.autograd.Function):
+    """x @ W + b over the B Z^2 pair rows; the weight gradient is a split-K GEMM (a plain X^T G call picks a tile shape
+    for a square problem and runs 20x slower at P = 65536)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return torch.addmm(b, x.reshape(-1, x.shape[-1]), W).view(*x.shape[:-1], W.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = (g2 @ W.t()).view(x.shape) if ctx.needs_input_grad[0] else None
+        dW = _xt_dot(x.reshape(-1, x.shape[-1]), g2) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
 class _SepGconv(torch.autograd.Function):
     """out[b,r,:] = bias + sum_s a[b,s,:] * (kb[b,r,s,:] @ W)   (SepGconv.__call__, ponita_ode_g.py:63-83)."""
 
@@ -60,8 +95,7 @@ class _SepGconv(torch.autograd.Function):
             dkb = torch.empty_like(kb)
             _lib.check(lib.enf_ode_conv_backward_basis(B, Z, J, C, _ptr(a), _ptr(g), _ptr(W), _ptr(dkb), st))
         if ctx.needs_input_grad[2]:       # d W = kb^T (g (x) a) over the pair axis: a plain GEMM
-            v = (g[:, :, None, :] * a[:, None, :, :]).reshape(-1, C)
-            dW = kb.reshape(-1, J).t() @ v
+            dW = _xt_dot(kb.reshape(-1, J), (g[:, :, None, :] * a[:, None, :, :]).reshape(-1, C))
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = g.sum((0, 1))
         return da, dkb, dW, db
@@ -152,7 +186,8 @@ class PonitaGen:
         if inv.num_z_ori_dims > 0:                                                        # :152-155
             p = torch.cat((p[..., :zp], torch.cos(p[..., zp:]), torch.sin(p[..., zp:])), -1)
         invariants = inv(p, p)                                                            # (B, Z, Z, I)
-        kb = _gelu(_dense(_gelu(_dense(self.poly(invariants), P["kernel_basis"]["layers_1"])), P["kernel_basis"]["layers_3"]))
+        K1, K3 = P["kernel_basis"]["layers_1"], P["kernel_basis"]["layers_3"]
+        kb = _gelu(_PairDense.apply(_gelu(_PairDense.apply(self.poly(invariants), K1["kernel"], K1["bias"])), K3["kernel"], K3["bias"]))
         if self.kernel_size != "global":                                                  # :162-164
             kb = kb * torch.exp(-torch.linalg.norm(p[:, :, None, :] - p[:, None, :, :], dim=-1) / self.kernel_size)[..., None]
         a = _dense(a, P["a_stem"])
