@@ -370,6 +370,42 @@ class MetaSGDPDETrainer:
         return flat[-1][0], TrainState(params=params, nef_opt_state=nef_opt_state, autodecoder_opt_state=state.autodecoder_opt_state,
                                        meta_sgd_opt_state=lr_state, ode_opt_state=ode_opt_state, step=state.step + 1, rng=state.rng)
 
+    def select_train_step(self, epoch):
+        """The phase schedule of _base_pde_trainer.py:280-299: nef while training.nef.train_from_epoch < epoch <=
+        train_until_epoch, ode likewise, both -> dual.  Returns the bound step function; every step takes
+        (state, trajectory) -- the nef phase fits the frames nef_loss picks (_nef_frames)."""
+        t = self.config.training
+        train_nef = t.nef.train_from_epoch < epoch <= t.nef.train_until_epoch
+        train_ode = self.ode_model is not None and t.ode.train_from_epoch < epoch <= t.ode.train_until_epoch
+        if train_nef and train_ode:
+            return self.dual_train_step
+        if train_nef:
+            return lambda state, trajectory, **kw: self.nef_train_step(state, self._nef_frames(state, trajectory), **kw)
+        if train_ode:
+            return self.ode_train_step
+        raise ValueError("No training step set")
+
+    def _nef_frames(self, state, trajectory):
+        """nef_loss's choice of frames (pde_trainer.py:483-497): the first frame, or ``fit_on_num_steps`` random training
+        frames of every trajectory, each fitted as a signal of its own."""
+        k = getattr(getattr(self.config.training, "nef", None), "fit_on_num_steps", 1)
+        if k == 1:
+            return trajectory[:, 0]
+        idx = torch.randperm(self.config.dataset.traj_len_train, generator=state.rng)[:k].to(trajectory.device)
+        sub = trajectory[:, idx]
+        return sub.reshape(sub.shape[0] * sub.shape[1], *sub.shape[2:])
+
+    def train_epoch(self, state, loader, epoch):
+        """One pass over ``loader`` (an iterable of trajectories (B, T, *grid, O) or of the reference's
+        (trajectory, _, _) batches) with the step the schedule selects; returns (mean loss, state)."""
+        step = self.select_train_step(epoch)
+        total, n = 0.0, 0
+        for batch in loader:
+            trajectory = batch[0] if isinstance(batch, (tuple, list)) else batch
+            loss, state = step(state, trajectory)
+            total, n = total + float(loss), n + 1
+        return total / max(n, 1), state
+
     @torch.no_grad()
     def val_step(self, state, trajectory, initial_state_dp=0.0, masks=None):
         """pde_trainer.py:360-409: fit the first frame, roll out over train + out-of-horizon frames, decode the full grid;

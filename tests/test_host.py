@@ -268,3 +268,31 @@ def test_ode_host_pieces_on_cpu():
     cfg.node.name = "gru"
     with pytest.raises(ValueError, match="Unknown ODE model"):
         get_model_pde(cfg)
+
+
+def test_trainer_phase_schedule():
+    """_base_pde_trainer.py:280-299 with config_navier_stokes.yaml's epochs (nef 0..500, ode 500..2000)."""
+    from enf_pde_amd.fitting.trainers import MetaSGDPDETrainer
+    tr = MetaSGDPDETrainer.__new__(MetaSGDPDETrainer)
+    tr.config = NS(training=NS(nef=NS(train_from_epoch=0, train_until_epoch=500), ode=NS(train_from_epoch=500, train_until_epoch=2000)))
+    tr.ode_model = object()
+    assert tr.select_train_step(2000) == tr.ode_train_step and tr.select_train_step(501) == tr.ode_train_step
+    assert tr.select_train_step(1).__name__ == "<lambda>" and tr.select_train_step(500).__name__ == "<lambda>"    # nef phase
+    with pytest.raises(ValueError, match="No training step set"):
+        tr.select_train_step(0)                                    # the reference starts counting epochs at 1
+    with pytest.raises(ValueError):
+        tr.select_train_step(2001)
+    tr.config.training.nef.train_until_epoch = 800
+    assert tr.select_train_step(600) == tr.dual_train_step
+    tr.ode_model = None
+    assert tr.select_train_step(600).__name__ == "<lambda>"
+    import torch
+    traj = torch.arange(2 * 10 * 4 * 4, dtype=torch.float32).reshape(2, 10, 4, 4, 1)
+    st = NS(rng=torch.Generator().manual_seed(0))
+    assert torch.equal(tr._nef_frames(st, traj), traj[:, 0])                       # fit_on_num_steps absent -> 1
+    tr.config.training.nef.fit_on_num_steps = 2                                    # config_ihc.yaml
+    tr.config.dataset = NS(traj_len_train=6)
+    fr = tr._nef_frames(st, traj)
+    assert fr.shape == (4, 4, 4, 1)
+    ids = {int(f[0, 0, 0]) // 16 % 10 for f in fr}
+    assert len(ids) == 2 and max(ids) < 6                                          # two distinct training frames
