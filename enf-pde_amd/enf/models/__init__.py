@@ -17,7 +17,7 @@ from ..steerable_attention.invariant import BaseInvariant
 from ... import _lib
 from . import _pad
 
-__all__ = ["EquivariantCrossAttentionNeF", "TENSOR_PATHS"]
+__all__ = ["EquivariantCrossAttentionNeF", "TENSOR_PATHS", "tensor_paths"]
 
 _BLK = "cross_attention_blocks_0"
 # ENF_W_* order of include/enf_hip.h -> path in the Flax parameter tree
@@ -52,6 +52,12 @@ TENSOR_PATHS = [
     ("out_proj", "layers_4", "kernel"), ("out_proj", "layers_4", "bias"),
 ]
 assert len(TENSOR_PATHS) == _lib.ENF_NUM_TENSORS
+BLOCK_PATHS = [t[1:] for t in TENSOR_PATHS if t[0] == _BLK]       # the 38 tensors of one attention block
+
+
+def tensor_paths(num_layers=0):
+    """TENSOR_PATHS followed by the tensors of the latent self-attention blocks (NEF:137-167), layer by layer."""
+    return TENSOR_PATHS + [(f"self_attention_blocks_{i}",) + t for i in range(num_layers) for t in BLOCK_PATHS]
 
 
 def _get(tree, path):
@@ -140,9 +146,6 @@ class EquivariantCrossAttentionNeF:
                 raise NotImplementedError(f"embedding type '{embedding_type}' is outside the accelerated path "
                                           "(no shipped config selects it; SURVEY.md 2, row 2)")
             raise ValueError(f"Unknown embedding type: {embedding_type}.")          # EMB:33
-        if num_layers != 0:
-            raise NotImplementedError("latent self-attention layers (num_layers > 0) are not on the accelerated "
-                                      "path: every shipped config runs num_layers=0 (SURVEY.md 0.3)")
         if not condition_value_transform:
             raise NotImplementedError("condition_value_transform=False is not on the accelerated path")
         assert not num_hidden % 2, "For the Fourier Features hidden_dim should be even to calculate them correctly."  # RFF:75-77
@@ -156,6 +159,14 @@ class EquivariantCrossAttentionNeF:
         self.num_out, self.latent_dim = int(num_out), int(latent_dim)
         self.cross_attn_invariant = cross_attn_invariant
         self.self_attn_invariant = self_attn_invariant if self_attn_invariant is not None else cross_attn_invariant
+        if self.num_layers > 0:
+            # latent self-attention (NEF:223-226) runs the same pair kernels with the latents' own positions as queries
+            # (enf/models/_train.py: apply_layers); dormant in every shipped config, so only the plain shapes are served
+            if self.self_attn_invariant.name not in _lib.INVARIANT_IDS:
+                raise NotImplementedError(f"self-attention with the '{self.self_attn_invariant.name}' invariant (queries "
+                                          "that carry an orientation) is not built")
+            if self._Dp != self.num_hidden or self._Hp != self.num_heads:
+                raise NotImplementedError("num_layers > 0 is served at the kernels' native widths / head counts only")
         self.embedding_type = embedding_type
         self.embedding_freq_multiplier = tuple(embedding_freq_multiplier)
         self.condition_value_transform = condition_value_transform
@@ -246,28 +257,40 @@ class EquivariantCrossAttentionNeF:
         P = {"latent_stem": lecun(C, D),
              _BLK: {"layer_norm_attn": ln(D), "attn": attn, "pointwise_ffn": ffn(HD, HD, HD)},
              "out_proj": {"layers_0": lecun(HD, D), "layers_2": lecun(D, D), "layers_4": lecun(D, O)}}
+        Is = self.self_attn_invariant.dim
+        for i in range(self.num_layers):                                 # NEF:137-167 (project_heads=True: widths D)
+            def rff_s(std):
+                r = rff(std)
+                r["encoding"]["coefficients"] = normal((Is, D // 2), std)
+                return r
+            P[f"self_attention_blocks_{i}"] = {
+                "layer_norm_attn": ln(D),
+                "attn": {"invariant_embedding_query": rff_s(fq), "invariant_embedding_value": rff_s(fv),
+                         "inv_emb_to_q": lecun(D, HD), "a_to_k": lecun(D, HD), "a_to_v": lecun(D, HD),
+                         "inv_emb_to_v": ffn(D, D, 2 * HD), "inv_emb_cond_mixer": ffn(D, D, D), "out_proj": lecun(HD, D)},
+                "pointwise_ffn": ffn(D, D, D)}
 
         def to_dev(t):
             return {k: to_dev(v) for k, v in t.items()} if isinstance(t, dict) else t.to(device=device, dtype=torch.float32)
         return {"params": to_dev(P)}
 
     def param_tensors(self, params):
-        """The ENF_NUM_TENSORS weight tensors in C-ABI order."""
+        """The ENF_NUM_TENSORS weight tensors in C-ABI order (then, for num_layers > 0, 38 per self-attention block)."""
         P = params["params"] if "params" in params else params
-        return [_get(P, path) for path in TENSOR_PATHS]
+        return [_get(P, path) for path in tensor_paths(self.num_layers)]
 
     def load_params(self, tree, device="cuda"):
         """Build a parameter tree from nested numpy / torch arrays (e.g. an exported Flax tree)."""
         P = tree["params"] if "params" in tree else tree
         out = {}
-        for path in TENSOR_PATHS:
+        for path in tensor_paths(self.num_layers):
             _set(out, path, torch.as_tensor(_get(P, path)).to(device=device, dtype=torch.float32).contiguous())
         return {"params": out}
 
     def pack(self, params):
         """Packed weight blob (device uint8 tensor) for ``params``; cached until a tensor changes."""
         lib = _lib.load()
-        ts = self.param_tensors(params)
+        ts = self.param_tensors(params)[:_lib.ENF_NUM_TENSORS]
         dev = ts[0].device
         if dev.type != "cuda":
             raise _lib.EnfError("parameters must live on the GPU: the decoder has no CPU path")
@@ -330,6 +353,10 @@ class EquivariantCrossAttentionNeF:
         if sigma is not None:
             sigma = sigma.float().reshape(p.shape[0], p.shape[1], 1)
         ts = self.param_tensors(params)
+        if self.num_layers > 0:
+            from . import _train
+            self._check_shapes(ts)
+            return _train.apply_layers(self, ts, x, p, a, sigma)
         if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
             # training path: gradients w.r.t. the weights as well (TR:255, NTR:304-339)
             from . import _train
@@ -348,6 +375,15 @@ class EquivariantCrossAttentionNeF:
         Returns (loss (1,), dp, da, dwindow or None)."""
         lib = _lib.load()
         sigma = gaussian_window_size if self.use_gaussian_window else None
+        if self.num_layers > 0:           # no fused sequence for the layered model: autograd through apply()
+            with torch.enable_grad():
+                leaves = [a.detach().float().requires_grad_(True)] + \
+                         ([sigma.detach().float().requires_grad_(True)] if sigma is not None else [])
+                out = self.apply(params, x, p.detach(), leaves[0], leaves[1] if sigma is not None else None)
+                loss = ((out - target) ** 2).mean()
+                g = torch.autograd.grad(loss * grad_scale, leaves, allow_unused=True)
+            g = [torch.zeros_like(t) if gi is None else gi for t, gi in zip(leaves, g)]
+            return loss.detach().reshape(1), None, g[0], (g[1] if sigma is not None else None)   # no pose gradient (see apply_layers)
         packed = self.pack(params)
         x, p_, a_ = x.float(), p.float().contiguous(), a.float().contiguous()
         s_ = sigma.float().reshape(p_.shape[0], p_.shape[1], 1).contiguous() if sigma is not None else None

@@ -175,13 +175,14 @@ def _gelu(x):
     return Fnn.gelu(x, approximate="tanh")      # flax nn.gelu default
 
 
-def latent_table(model, W, p, a, sigma, lay):
+def latent_table(model, W, p, a, sigma, lay, stem=True, inv=None):
     """K1 as differentiable ops: stem, LayerNorm, k / v0, the logit fold (u, c), pose embedding
-    and window coefficient, laid out as the pair kernels' latent table (enf_lt_layout)."""
+    and window coefficient, laid out as the pair kernels' latent table (enf_lt_layout).
+    stem=False: ``a`` is already in the hidden space (layers after the stem, NEF:223-229)."""
     H, D = model._Hp, model._Dp
     B, Z = p.shape[:2]
-    inv = model.cross_attn_invariant
-    s = a @ W["stem_w"] + W["stem_b"]                                     # NEF:220
+    inv = inv if inv is not None else model.cross_attn_invariant
+    s = a @ W["stem_w"] + W["stem_b"] if stem else a                      # NEF:220
     an = _ln(s, W["lna_g"], W["lna_b"], model.num_hidden)                 # NEF:56 / ECB
     k = (an @ W["k_w"] + W["k_b"]).view(B, Z, H, D)                       # ECA:93
     v0 = an @ W["v_w"] + W["v_b"]                                         # ECA:94
@@ -264,6 +265,57 @@ W_NAMES = ["stem_w", "stem_b", "lna_g", "lna_b",
            "ao_w", "ao_b", "ff_w0", "ff_b0", "ff_g", "ff_be", "ff_w1", "ff_b1",
            "o0_w", "o0_b", "o2_w", "o2_b", "o4_w", "o4_b"]      # ENF_W_* order
 assert len(W_NAMES) == _lib.ENF_NUM_TENSORS
+
+
+class _SelfAttnView:
+    """The pair kernels' descriptor for a latent self-attention block: queries = the latents' own positions, the
+    self-attention invariant (NEF:223-226)."""
+
+    def __init__(self, model):
+        self._m = model
+        self._Hp, self._Dp, self.precision = model._Hp, model._Dp, model.precision
+        self.num_hidden, self.num_heads = model.num_hidden, model.num_heads
+        self._x_arg = model._x_arg
+
+    def _desc(self, B, N, Z):
+        m, inv = self._m, self._m.self_attn_invariant
+        return _lib.make_desc(B, N, Z, m._Hp, m._Dp, m.latent_dim, m.num_out, inv.num_x_pos_dims, inv.kernel_id,
+                              m.use_gaussian_window, _lib.PREC[m.precision])
+
+
+def apply_layers(model, tensors, x, p, a, sigma):
+    """nef.apply with num_layers > 0 (NEF:204-235): stem, the latent self-attention blocks -- each one the attention
+    operator over (p, p) on the HIP pair kernels between differentiable per-latent ops --, then the cross-attention
+    block on the hidden latents and the output MLP.  Differentiable w.r.t. a, gaussian_window and every weight."""
+    if torch.is_grad_enabled() and p.requires_grad:
+        # a self-attention block's queries ARE the latent positions; the pair backward returns the latent-side gradient only
+        raise NotImplementedError("d/d(latent poses) through self-attention layers needs the pair kernel's query-side "
+                                  "gradient: not built (d/d a, d/d gaussian_window and d/d weights are)")
+    n0 = _lib.ENF_NUM_TENSORS
+    W = dict(zip(W_NAMES, tensors[:n0]))
+    blk = W_NAMES[2:40]                                                    # the 38 tensors of one attention block
+    D, HD = model.num_hidden, model.num_heads * model.num_hidden
+    B, Z = p.shape[:2]
+    sa = model.self_attn_invariant
+    s = a @ W["stem_w"] + W["stem_b"]                                     # NEF:220
+    view = _SelfAttnView(model)
+    xq = p[..., :sa.num_x_pos_dims].contiguous()                          # queries of a self-attention block: x = p
+    lay = lt_layout(view._desc(B, Z, Z))
+    for i in range(model.num_layers):
+        Wi = dict(zip(blk, tensors[n0 + 38 * i:n0 + 38 * (i + 1)]))
+        lt = latent_table(view, Wi, p, s, sigma, lay, stem=False, inv=sa)
+        ybar = _PairFunction.apply(xq, lt, view, *effective_pair_params(view, Wi))            # (B, Z, HD)
+        y = ybar.view(B, Z, model.num_heads, D) * Wi["mx_g"] + Wi["mx_be"]
+        y = (y @ Wi["mx_w1"] + Wi["mx_b1"]).reshape(B, Z, HD)                                  # ECA:16-21 (mixer Dense_1)
+        a_attn = y @ Wi["ao_w"] + Wi["ao_b"]                                                   # ECA:150 (project_heads: HD -> D)
+        r = s + a_attn                                                                         # NEF:62-64 (residual)
+        f = _ln(_gelu(r @ Wi["ff_w0"] + Wi["ff_b0"]), Wi["ff_g"], Wi["ff_be"], D) @ Wi["ff_w1"] + Wi["ff_b1"]
+        s = _gelu(s + f)                                                                       # NEF:225-226
+    desc = model._desc(B, x.shape[1], Z)
+    _lib.check(_lib.load().enf_check_desc(ctypes.byref(desc)))
+    lt = latent_table(model, W, p, s, sigma, lt_layout(desc), stem=False)
+    ybar = _PairFunction.apply(x, lt, model, *effective_pair_params(model, W))
+    return tail(model, W, ybar)
 
 
 def apply_train(model, tensors, x, p, a, sigma):

@@ -38,7 +38,7 @@ from ..inner_loop import _pose, make_masks, inner_loop, decode
 from .trainer_utils.solvers import solve_latent_ode
 from ..optim import Adam, AdamW, clip_by_global_norm
 from ..parallel import allreduce_mean_
-from ...enf.models import TENSOR_PATHS, _get, _set
+from ...enf.models import TENSOR_PATHS, BLOCK_PATHS, tensor_paths, _get, _set
 
 LATENT_KEYS = ("p_pos", "p_ori", "a", "gaussian_window")
 
@@ -61,7 +61,8 @@ def _unflatten(tree, leaves):
 
 def _tree_from_tensors(tensors):
     out = {}
-    for path, t in zip(TENSOR_PATHS, tensors):
+    layers = (len(tensors) - len(TENSOR_PATHS)) // len(BLOCK_PATHS)       # self-attention blocks, if any
+    for path, t in zip(tensor_paths(layers), tensors):
         _set(out, path, t)
     return {"params": out}
 

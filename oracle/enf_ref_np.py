@@ -190,12 +190,25 @@ def gaussian_window(name, x, p, sigma, num_in=2):
 
 
 # --------------------------------------------------------------------------- operator + model
-def cross_attention(pa, cfg, x, p, a, sigma, return_aux=False):
-    """ECA:74-151 with condition_value_transform=True, condition_invariant_embedding=False,
-    project_heads=False (NEF:171-179)."""
+def sa_invariant(name, p):
+    """Self-attention invariant of (p, p) (INV/__init__.py:13-44): the cross-attention classes, except 'ponita' ->
+    Ponita2D (INV/ponita.py:64-92: both sides carry an orientation; p = (pos, cos, sin)).  Axis 1 = the 'x' side."""
+    if name == "ponita":
+        rel = p[:, :, None, :2] - p[:, None, :, :2]
+        ori_x, ori_p = p[:, :, None, 2:], p[:, None, :, 2:]
+        i1 = rel[..., 0] * ori_p[..., 0] + rel[..., 1] * ori_p[..., 1]
+        i2 = -rel[..., 0] * ori_p[..., 1] + rel[..., 1] * ori_p[..., 0]
+        return np.stack([i1, i2, (ori_x * ori_p).sum(-1)], -1)
+    return invariant(name, p, p)
+
+
+def cross_attention(pa, cfg, x, p, a, sigma, return_aux=False, self_attn=False):
+    """ECA:74-151 with condition_value_transform=True, condition_invariant_embedding=False (NEF:101-126);
+    project_heads only changes out_proj's width (ECA:69-72).  self_attn: x is p and the invariant is the
+    self-attention one (NEF:223-226)."""
     H, D = cfg["num_heads"], cfg["num_hidden"]
     name = cfg["invariant"]
-    inv = invariant(name, x, p)                                     # ECA:86
+    inv = sa_invariant(name, p) if self_attn else invariant(name, x, p)   # ECA:86
     emb_q = rff_net(inv, pa["invariant_embedding_query"])          # ECA:89
     q = dense(emb_q, pa["inv_emb_to_q"])                           # ECA:92  (B,N,Z,HD)
     k = dense(a, pa["a_to_k"])                                     # ECA:93  (B,Z,HD)
@@ -225,7 +238,7 @@ def cross_attention(pa, cfg, x, p, a, sigma, return_aux=False):
 
 
 def nef_apply(params, cfg, x, p, a, sigma):
-    """EquivariantCrossAttentionNeF.__call__ (NEF:204-235) with num_layers == 0.
+    """EquivariantCrossAttentionNeF.__call__ (NEF:204-235).
 
     x (B,N,dx)  p (B,Z,z_pos+z_ori)  a (B,Z,C)  sigma (B,Z,1)  ->  (B,N,O)
     """
@@ -236,8 +249,10 @@ def nef_apply(params, cfg, x, p, a, sigma):
         zp = spec["z_pos"]
         p = np.concatenate([p[:, :, :zp], np.cos(p[:, :, zp:]), np.sin(p[:, :, zp:])], axis=-1)
     a = dense(a, P["latent_stem"])                                 # NEF:220
-    if cfg.get("num_layers", 0) != 0:
-        raise NotImplementedError("self-attention layers: every shipped config has num_layers=0")
+    for i in range(cfg.get("num_layers", 0)):                      # NEF:223-226, block NEF:43-68 (residual=True)
+        sb = P[f"self_attention_blocks_{i}"]
+        a_attn = cross_attention(sb["attn"], cfg, p, p, layer_norm(a, sb["layer_norm_attn"]), sigma, self_attn=True)
+        a = gelu(a + pointwise_ffn(a + a_attn, sb["pointwise_ffn"]))
     blk = P["cross_attention_blocks_0"]
     a_norm = layer_norm(a, blk["layer_norm_attn"])                 # NEF:56
     att = cross_attention(blk["attn"], cfg, x, p, a_norm, sigma)   # NEF:59
@@ -310,15 +325,17 @@ def init_params(seed, cfg, jitter=0.0):
     assert D % 2 == 0, "For the Fourier Features hidden_dim should be even"  # RFF:75-77
     fq, fv = cfg["embedding_freq_multiplier"]
     HD = H * D
-    attn = {
-        "invariant_embedding_query": _rff_init(rng, I, D, fq),
-        "invariant_embedding_value": _rff_init(rng, I, D, fv),
-        "inv_emb_to_q": _dense_init(rng, D, HD), "a_to_k": _dense_init(rng, D, HD),
-        "a_to_v": _dense_init(rng, D, HD),
-        "inv_emb_to_v": _ffn_init(rng, D, D, 2 * HD, jitter),
-        "inv_emb_cond_mixer": _ffn_init(rng, D, D, D, jitter),
-        "out_proj": _dense_init(rng, HD, HD),
-    }
+    def attn_init(I_, n_proj):
+        return {
+            "invariant_embedding_query": _rff_init(rng, I_, D, fq),
+            "invariant_embedding_value": _rff_init(rng, I_, D, fv),
+            "inv_emb_to_q": _dense_init(rng, D, HD), "a_to_k": _dense_init(rng, D, HD),
+            "a_to_v": _dense_init(rng, D, HD),
+            "inv_emb_to_v": _ffn_init(rng, D, D, 2 * HD, jitter),
+            "inv_emb_cond_mixer": _ffn_init(rng, D, D, D, jitter),
+            "out_proj": _dense_init(rng, HD, n_proj),
+        }
+    attn = attn_init(I, HD)
     P = {
         "latent_stem": _dense_init(rng, C, D),
         "cross_attention_blocks_0": {"layer_norm_attn": _ln_init(D, rng, jitter), "attn": attn,
@@ -326,6 +343,10 @@ def init_params(seed, cfg, jitter=0.0):
         "out_proj": {"layers_0": _dense_init(rng, HD, D), "layers_2": _dense_init(rng, D, D),
                      "layers_4": _dense_init(rng, D, O)},
     }
+    I_sa = 3 if cfg["invariant"] == "ponita" else I                # Ponita2D (INV/ponita.py:61)
+    for i in range(cfg.get("num_layers", 0)):                      # NEF:137-167: project_heads=True -> widths D
+        P[f"self_attention_blocks_{i}"] = {"layer_norm_attn": _ln_init(D, rng, jitter), "attn": attn_init(I_sa, D),
+                                           "pointwise_ffn": _ffn_init(rng, D, D, D, jitter)}
     if jitter:
         def jit(d):
             for k, v in d.items():

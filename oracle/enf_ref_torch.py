@@ -123,9 +123,18 @@ def gaussian_window(name, x, p, sigma, num_in=2):
     raise ValueError(kind)
 
 
-def cross_attention(pa, cfg, x, p, a, sigma):
+def sa_invariant(name, p):
+    if name == "ponita":                            # Ponita2D, INV/ponita.py:64-92 (p = (pos, cos, sin))
+        rel = p[:, :, None, :2] - p[:, None, :, :2]
+        ox, op = p[:, :, None, 2:], p[:, None, :, 2:]
+        return torch.stack([rel[..., 0] * op[..., 0] + rel[..., 1] * op[..., 1],
+                            -rel[..., 0] * op[..., 1] + rel[..., 1] * op[..., 0], (ox * op).sum(-1)], -1)
+    return invariant(name, p, p)
+
+
+def cross_attention(pa, cfg, x, p, a, sigma, self_attn=False):
     H, D, name = cfg["num_heads"], cfg["num_hidden"], cfg["invariant"]
-    inv = invariant(name, x, p)
+    inv = sa_invariant(name, p) if self_attn else invariant(name, x, p)
     q = dense(rff_net(inv, pa["invariant_embedding_query"]), pa["inv_emb_to_q"])
     k = dense(a, pa["a_to_k"])
     v = dense(a, pa["a_to_v"])
@@ -150,13 +159,17 @@ def cross_attention(pa, cfg, x, p, a, sigma):
 
 
 def nef_apply(params, cfg, x, p, a, sigma):
-    """NEF:204-235 (num_layers == 0).  All tensors share one dtype/device."""
+    """NEF:204-235.  All tensors share one dtype/device."""
     P = params["params"]
     spec = invariant_spec(cfg["invariant"], cfg.get("num_in", 2))
     if spec["z_ori"] > 0:
         zp = spec["z_pos"]
         p = torch.cat([p[:, :, :zp], torch.cos(p[:, :, zp:]), torch.sin(p[:, :, zp:])], dim=-1)
     a = dense(a, P["latent_stem"])
+    for i in range(cfg.get("num_layers", 0)):                       # NEF:223-226
+        sb = P[f"self_attention_blocks_{i}"]
+        a_attn = cross_attention(sb["attn"], cfg, p, p, layer_norm(a, sb["layer_norm_attn"]), sigma, self_attn=True)
+        a = gelu(a + pointwise_ffn(a + a_attn, sb["pointwise_ffn"]))
     blk = P["cross_attention_blocks_0"]
     att = cross_attention(blk["attn"], cfg, x, p, layer_norm(a, blk["layer_norm_attn"]), sigma)
     out = gelu(pointwise_ffn(att, blk["pointwise_ffn"]))

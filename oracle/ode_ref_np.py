@@ -30,17 +30,7 @@ def sa_invariant_spec(name, num_in=2):
     return s
 
 
-def sa_invariant(name, p):
-    """invariants = self.invariant(p, p)  (PODE:158): axis 1 = the 'x' (receiver) side, axis 2 = the 'p' (sender) side.
-    For 'ponita' p is already expanded to (pos, cos, sin)  (PODE:152-155)."""
-    if name == "ponita":                            # Ponita2D.__call__, INV/ponita.py:64-92
-        rel = p[:, :, None, :2] - p[:, None, :, :2]
-        ori_x, ori_p = p[:, :, None, 2:], p[:, None, :, 2:]
-        i1 = rel[..., 0] * ori_p[..., 0] + rel[..., 1] * ori_p[..., 1]
-        i2 = -rel[..., 0] * ori_p[..., 1] + rel[..., 1] * ori_p[..., 0]
-        i3 = (ori_x * ori_p).sum(-1)
-        return np.stack([i1, i2, i3], -1)
-    return R.invariant(name, p, p)
+sa_invariant = R.sa_invariant        # (p, p) invariants, axis 1 = receiver side (PODE:158; p already expanded for 'ponita')
 
 
 def poly_features(x, degree):

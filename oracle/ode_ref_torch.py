@@ -12,14 +12,7 @@ from . import enf_ref_torch as T
 from .ode_ref_np import sa_invariant_spec
 
 
-def sa_invariant(name, p):
-    if name == "ponita":                            # Ponita2D, INV/ponita.py:64-92 (p = (pos, cos, sin))
-        rel = p[:, :, None, :2] - p[:, None, :, :2]
-        ox, op = p[:, :, None, 2:], p[:, None, :, 2:]
-        return torch.stack([rel[..., 0] * op[..., 0] + rel[..., 1] * op[..., 1],
-                            -rel[..., 0] * op[..., 1] + rel[..., 1] * op[..., 0],
-                            (ox * op).sum(-1)], -1)
-    return T.invariant(name, p, p)
+sa_invariant = T.sa_invariant
 
 
 def poly_features(x, degree):                       # PODE:22-26

@@ -108,8 +108,9 @@ def test_model_constructor_errors():
         _nef(embedding_type="siren")
     with pytest.raises(NotImplementedError):
         _nef(embedding_type="polynomial")
+    assert len(_nef(num_layers=2).init(0, device="cpu")["params"]) == 5          # + self_attention_blocks_0/1 (NEF:137-167)
     with pytest.raises(NotImplementedError):
-        _nef(num_layers=2)
+        _nef(num_layers=1, num_hidden=32)                                          # layers: native kernel widths only
     with pytest.raises(AssertionError):
         _nef(num_hidden=63)
 
