@@ -37,7 +37,7 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
     B = img.shape[0]
     S = masks.shape[1] - 1
     n_ori = nef.cross_attn_invariant.num_z_ori_dims
-    lat = {k: v.detach().repeat_interleave(B, dim=0).clone() for k, v in latents0.items()}   # pde_trainer.py:157-159
+    lat = {k: v.detach().repeat_interleave(B, dim=0) for k, v in latents0.items()}           # pde_trainer.py:157-159 (a fresh tensor)
     if noise_pos:                                                                             # pde_trainer.py:162-167
         lat["p_pos"] = lat["p_pos"] + torch.randn(lat["p_pos"].shape, generator=generator,
                                                   device="cpu").to(lat["p_pos"].device) * noise_pos
@@ -47,7 +47,7 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
     ys_all = img[:, masks.t()].transpose(0, 1).contiguous()              # (S+1, B, N_s, O)
     n_pos = lat["p_pos"].shape[-1]
     # update coefficients -lr * B (pde_trainer.py:207,215-219); sigma only moves when asked to (pde_trainer.py:210-212)
-    coef = {k: -(lrs[k] * B) for k in lat}
+    coef = {k: lrs[k] * float(-B) for k in lat}
     for s in range(S):                                                  # pde_trainer.py:191
         xs = xs_all[s][None].expand(B, -1, -1)                          # stride-0 batch
         _, dp, da, dsig = nef.mse_value_and_latent_grads(nef_params, xs, _pose(lat, n_ori), lat["a"],
