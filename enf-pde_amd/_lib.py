@@ -15,7 +15,7 @@ INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic"
 EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
            "enf_backward_latents", "enf_backward_latents_ex", "enf_forward_stages", "enf_lt_layout", "enf_lt_layout_ext", "enf_pack_pair", "enf_pair_forward",
-           "enf_pair_backward", "enf_pair_scratch_bytes", "enf_set_zfold", "enf_set_zfold_bwd", "enf_mse_value_grad",
+           "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_set_zfold", "enf_set_zfold_bwd", "enf_mse_value_grad",
            "enf_ode_conv_forward", "enf_ode_conv_backward_basis"]
 ENF_NUM_PAIR_TENSORS = 12          # ENF_P_* of include/enf_hip.h
 (ENF_S_EQ, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0) = range(8)
@@ -79,6 +79,7 @@ def load():
     lib.enf_pair_scratch_bytes.argtypes = [dp]
     lib.enf_pair_forward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, sz, vp]
     lib.enf_pair_backward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp), vp]
+    lib.enf_pair_backward_ex.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp), vp, vp]
     for name in ("enf_debug_gemm", "enf_debug_pack"):
         getattr(lib, name).restype = ci
     lib.enf_debug_gemm.argtypes = [vp, vp, vp, ci, ci, ci, vp]

@@ -12,7 +12,7 @@ int enf_launch_prologue_bwd(const EnfDims&, const EnfLayout&, const char*, const
 int enf_launch_pair_fwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, float*, float*,
                         char*, float*, char*, int, int, hipStream_t);
 int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, const float*,
-                        const float*, const float*, float*, void* const*, const char*, const float*, hipStream_t);
+                        const float*, const float*, float*, void* const*, const char*, const float*, float*, hipStream_t);
 int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
 int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
                     int, hipStream_t);
@@ -175,7 +175,7 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
     if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ENF_ELAUNCH;
   }
   if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr,
-                                zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, st))) return rc;
+                                zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, nullptr, st))) return rc;
   if ((rc = enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st))) return rc;
   return ENF_OK;
 }
@@ -246,6 +246,12 @@ extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstr
 extern "C" int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
                                  const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
                                  void* stream) {
+  return enf_pair_backward_ex(d, x, x_bstride, lt, packed, lse, dybar, delta, dlt, store, nullptr, stream);
+}
+
+extern "C" int enf_pair_backward_ex(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                                    const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
+                                    float* dx, void* stream) {
   int rc = enf_check_desc(d);
   if (rc) return rc;
   if (!x || !lt || !packed || !lse || !dybar || !delta || !dlt) return ENF_EINVAL;
@@ -255,5 +261,5 @@ extern "C" int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bst
       if (!store[i]) return ENF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dlt, 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
-  return enf_launch_pair_bwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, lse, dybar, delta, dlt, store, nullptr, nullptr, st);
+  return enf_launch_pair_bwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, lse, dybar, delta, dlt, store, nullptr, nullptr, dx, st);
 }

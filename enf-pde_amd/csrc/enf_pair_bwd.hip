@@ -62,6 +62,7 @@ struct PairBwdArgs {
   void* store[ENF_NUM_STORE(4)];        // ENF_S_* buffers (STORE instantiation only)
   float inv_d;                          // 1 / (true num_hidden)
   const char* wzt; const float* wzb;    // ZF only: per (latent, head) [forward | backward] panels of W_zh, and c_zh
+  float* dxq;                           // (B, N, dx) or nullptr: gradient w.r.t. the query coordinates, accumulated (atomics)
   int B, N, Z, dx, inv, use_window, nsplit;
 };
 
@@ -184,8 +185,11 @@ DEV void gb_panel_flip(f32x4 (&v)[D / 16], f32x4 (&opgf)[D / 16], const Frags<BF
 template <bool FAST>
 DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& pz, float wcoef, int use_window,
                             const float (&inv)[4], float win, float (&dinv)[4], float dwin, float (&dpose)[4],
-                            float& dwc, float* dR = nullptr) {
+                            float& dwc, float* dR = nullptr, float* dxq = nullptr, const float* ext = nullptr) {
+  // dxq (3 values, or nullptr): the same pair's gradient w.r.t. the QUERY coordinates.  Where invariant and window depend
+  // on (x - p) only it is minus this pair's pose-position gradient; the spherical ones add their theta_x (and r_x) terms.
   const float PI = 3.14159265358979323846f;
+  const float dp0 = dpose[0], dp1 = dpose[1];
   switch (inv_id) {
     case ENF_INV_REL_POS_PERIODIC: {
       if (use_window) {                                   // win = wc (c0^2 + c1^2)
@@ -195,6 +199,7 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
       }
       dpose[0] += PI * (-inv[2] * dinv[0] + inv[0] * dinv[2]);   // d/dD0 [cos pi D0, sin pi D0], D = p - x
       dpose[1] += PI * (-inv[3] * dinv[1] + inv[1] * dinv[3]);
+      if (dxq) { dxq[0] = -(dpose[0] - dp0); dxq[1] = -(dpose[1] - dp1); dxq[2] = 0.f; }
     } break;
     case ENF_INV_BALL:                 // inv = [R x^ (3), r_x]: d R[i][j] += dinv[i] x^[j]   (dR: 9 per-lane sums)
     case ENF_INV_BALL_LAT:             // inv = [th_x, cd, sd, r_x]; th_p and r_p are latent-only rows (the phase)
@@ -226,6 +231,23 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
       dpose[2] += ddot * q.sx * cd;                        // d/d sin(theta_p)
       dpose[3] += ddot * q.cx;                             // d/d cos(theta_p)
       dpose[0] += dcd * sd - dsd * cd;                     // d cd/d phi_p = sd, d sd/d phi_p = -cd
+      if (dxq) {
+        dxq[0] = -(dcd * sd - dsd * cd);                   // phi_x enters through (phi_x - phi_p) ...
+        dxq[1] = ddot * (q.cx * pz[2] * cd - q.sx * pz[3]);   // d dot / d theta_x
+        dxq[2] = 0.f;
+        if (inv_id == ENF_INV_LATITUDE_PERIODIC || inv_id == ENF_INV_BALL_LAT) dxq[1] += dinv[0];   // inv[0] = theta_x
+        if (inv_id == ENF_INV_BALL_LAT) dxq[2] = dinv[3];                                           // inv[3] = r_x
+        if (inv_id == ENF_INV_BALL) {                      // ... and, for ball, through x^ in R x^: g = R^T dinv
+          const float xr = q.x0 * 0.15915494309189535f;
+          const float cp = cos_rev<FAST>(xr), sp = sin_rev<FAST>(xr);
+          const float g0 = ext[0] * dinv[0] + ext[3] * dinv[1] + ext[6] * dinv[2];
+          const float g1 = ext[1] * dinv[0] + ext[4] * dinv[1] + ext[7] * dinv[2];
+          const float g2 = ext[2] * dinv[0] + ext[5] * dinv[1] + ext[8] * dinv[2];
+          dxq[0] += q.sx * (-g0 * sp + g1 * cp);
+          dxq[1] += q.cx * (g0 * cp + g1 * sp) - q.sx * g2;
+          dxq[2] = dinv[3];
+        }
+      }
     } break;
     case ENF_INV_PONITA: {
       const float r0 = q.x0 - pz[0], r1 = q.x1 - pz[1];
@@ -239,6 +261,7 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
         dr1 += dwin * (-2.f * wcoef * r1);
       }
       dpose[0] -= dr0; dpose[1] -= dr1;
+      if (dxq) { dxq[0] = dr0; dxq[1] = dr1; dxq[2] = 0.f; }
     } break;
     default: {
       const float r0 = q.x0 - pz[0], r1 = dx > 1 ? q.x1 - pz[1] : 0.f, r2 = dx > 2 ? q.x2 - pz[2] : 0.f;
@@ -256,6 +279,10 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
       dpose[0] -= dr0;
       if (dx > 1) dpose[1] -= dr1;
       if (dx > 2) dpose[2] -= dr2;
+      if (dxq) {
+        dxq[0] = dr0; dxq[1] = dr1; dxq[2] = dr2;
+        if (inv_id == ENF_INV_ABS_POS) { dxq[0] += dinv[0]; dxq[1] += dinv[1]; dxq[2] += dinv[2]; }   // inv = x
+      }
     } break;
   }
 }
@@ -818,15 +845,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       float dwin = 0.f;
 #pragma unroll
       for (int h = 0; h < H; ++h) { dC[h] += dlogit[h]; dwin += dlogit[h]; }
+      float dxv[3];
+      float* dxp = A.dxq ? dxv : nullptr;
       if (has_ph) {
         float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, dR);
+        pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, dR, dxp, ext);
         if (A.inv == ENF_INV_BALL) {
 #pragma unroll
           for (int k = 0; k < 9; ++k) eacc[k * 16] += dR[k];
         }
       } else
-      pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc);
+      pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, nullptr, dxp);
+      if (A.dxq && nvalid && active) {          // every latent's wave adds its share to the query's gradient
+        float* o = A.dxq + ((size_t)b * A.N + n) * A.dx;
+        atomicAdd(o, dxv[0]);
+        if (A.dx > 1) atomicAdd(o + 1, dxv[1]);
+        if (A.dx > 2) atomicAdd(o + 2, dxv[2]);
+      }
     } else if (has_ph && quad == 1) { eacc[9 * 16] += dlat[0]; eacc[10 * 16] += dlat[1]; }
   }
 
@@ -889,8 +924,9 @@ static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
 
 extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, const float* lse, const float* dybar, const float* delta, float* dlt,
-                                   void* const* store, const char* wzt, const float* wzb, hipStream_t st) {
+                                   void* const* store, const char* wzt, const float* wzb, float* dxq, hipStream_t st) {
   PairBwdArgs A;
+  A.dxq = dxq;
   const bool zf = !store && wzt && wzb && (size_t)m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
   A.wzt = wzt; A.wzb = wzb; A.inv_d = 1.0f / (float)m.Dt;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;

@@ -331,7 +331,7 @@ class EquivariantCrossAttentionNeF:
         """nef.apply(params, x, p, a, gaussian_window) -> (B, N, num_out)   (NEF:204-235).
 
         x (B,N,dx) [stride-0 batch allowed], p (B,Z,z_pos+z_ori), a (B,Z,latent_dim),
-        gaussian_window_size (B,Z,1).  Differentiable w.r.t. p, a, gaussian_window_size.
+        gaussian_window_size (B,Z,1).  Differentiable w.r.t. p, a, gaussian_window_size, the weights and x.
         """
         inv = self.cross_attn_invariant
         if not (x.is_cuda and p.is_cuda and a.is_cuda):
@@ -357,8 +357,8 @@ class EquivariantCrossAttentionNeF:
             from . import _train
             self._check_shapes(ts)
             return _train.apply_layers(self, ts, x, p, a, sigma)
-        if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
-            # training path: gradients w.r.t. the weights as well (TR:255, NTR:304-339)
+        if torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in ts)):
+            # training path: gradients w.r.t. the weights (TR:255, NTR:304-339) and / or the query coordinates
             from . import _train
             self._check_shapes(ts)
             return _train.apply_train(self, ts, x, p, a, sigma)
@@ -377,13 +377,13 @@ class EquivariantCrossAttentionNeF:
         sigma = gaussian_window_size if self.use_gaussian_window else None
         if self.num_layers > 0:           # no fused sequence for the layered model: autograd through apply()
             with torch.enable_grad():
-                leaves = [a.detach().float().requires_grad_(True)] + \
+                leaves = [t.detach().float().requires_grad_(True) for t in (p, a)] + \
                          ([sigma.detach().float().requires_grad_(True)] if sigma is not None else [])
-                out = self.apply(params, x, p.detach(), leaves[0], leaves[1] if sigma is not None else None)
+                out = self.apply(params, x, leaves[0], leaves[1], leaves[2] if sigma is not None else None)
                 loss = ((out - target) ** 2).mean()
                 g = torch.autograd.grad(loss * grad_scale, leaves, allow_unused=True)
             g = [torch.zeros_like(t) if gi is None else gi for t, gi in zip(leaves, g)]
-            return loss.detach().reshape(1), None, g[0], (g[1] if sigma is not None else None)   # no pose gradient (see apply_layers)
+            return loss.detach().reshape(1), g[0], g[1], (g[2] if sigma is not None else None)
         packed = self.pack(params)
         x, p_, a_ = x.float(), p.float().contiguous(), a.float().contiguous()
         s_ = sigma.float().reshape(p_.shape[0], p_.shape[1], 1).contiguous() if sigma is not None else None

@@ -75,6 +75,64 @@ def _xt_dot(X, Dl):
     return out
 
 
+_NO_SPLIT = __import__("os").environ.get("ENF_TRAIN_SPLIT") == "0"      # A/B switch for the split-row reductions below
+
+
+def _col_sum(Dl):
+    """Column sums of Dl (P, D) in fp32.  For P >> D the generic reduction kernel runs at a quarter of the memory rate; a
+    batched ones-vector product over the same 4096-row slices as _xt_dot reads Dl at GEMM speed."""
+    P, D = Dl.shape
+    n = P // SPLIT_K
+    if n < 4 or _NO_SPLIT:
+        return Dl.sum(0, dtype=torch.float32)
+    ones = Dl.new_ones((n, 1, SPLIT_K))
+    Db = Dl[:n * SPLIT_K].view(n, SPLIT_K, D)
+    if Dl.dtype == torch.float32:
+        out = torch.bmm(ones, Db).sum((0, 1))
+    else:
+        try:
+            out = torch.bmm(ones, Db, out_dtype=torch.float32).sum((0, 1))
+        except (TypeError, RuntimeError, NotImplementedError):
+            return Dl.sum(0, dtype=torch.float32)
+    if n * SPLIT_K < P:
+        out = out + Dl[n * SPLIT_K:].sum(0, dtype=torch.float32)
+    return out
+
+
+def _xt_dot2(X, G):
+    """X^T @ G for X (P, K), G (P, N), fp32, split over the row axis when it is long (few output tiles otherwise)."""
+    P = X.shape[0]
+    n = P // SPLIT_K
+    if n < 2:
+        return X.t() @ G
+    out = torch.bmm(X[:n * SPLIT_K].view(n, SPLIT_K, -1).transpose(1, 2), G[:n * SPLIT_K].view(n, SPLIT_K, -1)).sum(0)
+    if n * SPLIT_K < P:
+        out = out + X[n * SPLIT_K:].t() @ G[n * SPLIT_K:]
+    return out
+
+
+class _RowDense(torch.autograd.Function):
+    """x @ W + b over many rows (the per-query tail: B N rows); weight / bias gradients as split-row products."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return torch.addmm(b, x.reshape(-1, x.shape[-1]), W).view(*x.shape[:-1], W.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = (g2 @ W.t()).view(x.shape) if ctx.needs_input_grad[0] else None
+        dW = _xt_dot2(x.reshape(-1, x.shape[-1]), g2) if ctx.needs_input_grad[1] else None
+        db = _col_sum(g2) if ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
+def _dense(x, W, b):
+    return _RowDense.apply(x, W, b) if x.numel() // x.shape[-1] >= 2 * SPLIT_K and not _NO_SPLIT else x @ W + b
+
+
 class _PairFunction(torch.autograd.Function):
     """ybar = softmax-weighted sum of the per-pair value chain; HIP forward and backward."""
 
@@ -101,6 +159,7 @@ class _PairFunction(torch.autograd.Function):
                                         _ptr(lse), _ptr(scratch), nscr, st))
         ctx.model, ctx.xstride, ctx.dims = model, xstride, (B, N, Z)
         ctx.need_w = any(ctx.needs_input_grad[3:])
+        ctx.x_shape = tuple(x.shape)
         ctx.save_for_backward(xb, lt_, blob, ybar, lse)
         ctx._keep = effc          # fp32 sources stay alive until the pack kernels have run
         return ybar
@@ -120,11 +179,16 @@ class _PairFunction(torch.autograd.Function):
         delta = (dybar * ybar).view(B, N, H, D).sum(-1).contiguous()
         dlt = torch.empty_like(lt)
         stride = lt.shape[1]
+        # gradient w.r.t. the query coordinates (self-attention blocks: the queries are the latent poses), on request
+        dxq = torch.zeros((B, N, ctx.x_shape[-1]), device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+
+        def dx_out():
+            return dxq          # (B, N, dx) also for a broadcast grid: autograd sums over the expand itself
         if not ctx.need_w:
             desc = model._desc(B, N, Z)
-            _lib.check(lib.enf_pair_backward(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(lt), _ptr(blob), _ptr(lse),
-                                             _ptr(dybar), _ptr(delta), _ptr(dlt), None, st))
-            return (None, dlt, None) + (None,) * _lib.ENF_NUM_PAIR_TENSORS
+            _lib.check(lib.enf_pair_backward_ex(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(lt), _ptr(blob), _ptr(lse),
+                                                _ptr(dybar), _ptr(delta), _ptr(dlt), None, _ptr(dxq), st))
+            return (dx_out(), dlt, None) + (None,) * _lib.ENF_NUM_PAIR_TENSORS
 
         bf16 = model.precision in ("bf16", "bfloat16")
         sdt = torch.bfloat16 if bf16 else torch.float32
@@ -145,22 +209,22 @@ class _PairFunction(torch.autograd.Function):
             sl = [store[i, :P] for i in range(ns)]
             arr = (ctypes.c_void_p * ns)(*[t.data_ptr() for t in sl])
             xo = xb if ctx.xstride == 0 else xb[b0:]
-            _lib.check(lib.enf_pair_backward(ctypes.byref(desc), _ptr(xo), ctx.xstride, _ptr(lt[b0 * Z:]), _ptr(blob),
-                                             _ptr(lse[b0:]), _ptr(dybar[b0:]), _ptr(delta[b0:]), _ptr(dlt[b0 * Z:]),
-                                             arr, st))
-            gAQ1 += _xt_dot(sl[S.ENF_S_EQ], sl[S.ENF_S_DA1]); gBQ1 += sl[S.ENF_S_DA1].sum(0, dtype=torch.float32)
-            gAV1 += _xt_dot(sl[S.ENF_S_EV], sl[S.ENF_S_DA2]); gBV1 += sl[S.ENF_S_DA2].sum(0, dtype=torch.float32)
-            gAF += _xt_dot(sl[S.ENF_S_G1], sl[S.ENF_S_DA3]); gBF += sl[S.ENF_S_DA3].sum(0, dtype=torch.float32)
+            _lib.check(lib.enf_pair_backward_ex(ctypes.byref(desc), _ptr(xo), ctx.xstride, _ptr(lt[b0 * Z:]), _ptr(blob),
+                                                _ptr(lse[b0:]), _ptr(dybar[b0:]), _ptr(delta[b0:]), _ptr(dlt[b0 * Z:]),
+                                                arr, _ptr(dxq[b0:] if dxq is not None else None), st))
+            gAQ1 += _xt_dot(sl[S.ENF_S_EQ], sl[S.ENF_S_DA1]); gBQ1 += _col_sum(sl[S.ENF_S_DA1])
+            gAV1 += _xt_dot(sl[S.ENF_S_EV], sl[S.ENF_S_DA2]); gBV1 += _col_sum(sl[S.ENF_S_DA2])
+            gAF += _xt_dot(sl[S.ENF_S_G1], sl[S.ENF_S_DA3]); gBF += _col_sum(sl[S.ENF_S_DA3])
             for h in range(H):
                 V, DA5, DG, DB = (sl[S.ENF_S_HEAD0 + 4 * h + i] for i in range(4))
-                gAM += _xt_dot(V, DA5); gBM += DA5.sum(0, dtype=torch.float32)
+                gAM += _xt_dot(V, DA5); gBM += _col_sum(DA5)
                 gAGB[:, h * D:(h + 1) * D] += _xt_dot(sl[S.ENF_S_NH], DG)
                 gAGB[:, HD + h * D:HD + (h + 1) * D] += _xt_dot(sl[S.ENF_S_NH], DB)
-                gBGB[h * D:(h + 1) * D] += DG.sum(0, dtype=torch.float32)
-                gBGB[HD + h * D:HD + (h + 1) * D] += DB.sum(0, dtype=torch.float32)
+                gBGB[h * D:(h + 1) * D] += _col_sum(DG)
+                gBGB[HD + h * D:HD + (h + 1) * D] += _col_sum(DB)
         assert dlt.shape[1] == stride
         # ENF_P_* order: AQ1,BQ1, AV1,BV1, AF,BF, AGB,BGB, AM,BM, COEFQ,COEFV (frozen: RFF:87-90)
-        return (None, dlt, None, gAQ1, gBQ1, gAV1, gBV1, gAF, gBF, gAGB, gBGB, gAM, gBM, None, None)
+        return (dx_out(), dlt, None, gAQ1, gBQ1, gAV1, gBV1, gAF, gBF, gAGB, gBGB, gAM, gBM, None, None)
 
 
 def _ln(x, g, b, n_true):
@@ -250,12 +314,13 @@ def tail(model, W, ybar):
     B, N, _ = ybar.shape
     y = ybar.view(B, N, H, D) * W["mx_g"] + W["mx_be"]
     y = (y @ W["mx_w1"] + W["mx_b1"]).reshape(B, N, H * D)               # ECA:16-21 (mixer Dense_1)
-    y = y @ W["ao_w"] + W["ao_b"]                                         # ECA out_proj
-    f = _ln(_gelu(y @ W["ff_w0"] + W["ff_b0"]), W["ff_g"], W["ff_be"], model.num_heads * model.num_hidden) @ W["ff_w1"] + W["ff_b1"]
+    y = _dense(y, W["ao_w"], W["ao_b"])                                   # ECA out_proj
+    f = _dense(_ln(_gelu(_dense(y, W["ff_w0"], W["ff_b0"])), W["ff_g"], W["ff_be"], model.num_heads * model.num_hidden),
+               W["ff_w1"], W["ff_b1"])
     o = _gelu(f)                                                          # NEF:227-233
-    o = _gelu(o @ W["o0_w"] + W["o0_b"])
-    o = _gelu(o @ W["o2_w"] + W["o2_b"])
-    return o @ W["o4_w"] + W["o4_b"]
+    o = _gelu(_dense(o, W["o0_w"], W["o0_b"]))
+    o = _gelu(_dense(o, W["o2_w"], W["o2_b"]))
+    return _dense(o, W["o4_w"], W["o4_b"])
 
 
 W_NAMES = ["stem_w", "stem_b", "lna_g", "lna_b",
@@ -286,11 +351,8 @@ class _SelfAttnView:
 def apply_layers(model, tensors, x, p, a, sigma):
     """nef.apply with num_layers > 0 (NEF:204-235): stem, the latent self-attention blocks -- each one the attention
     operator over (p, p) on the HIP pair kernels between differentiable per-latent ops --, then the cross-attention
-    block on the hidden latents and the output MLP.  Differentiable w.r.t. a, gaussian_window and every weight."""
-    if torch.is_grad_enabled() and p.requires_grad:
-        # a self-attention block's queries ARE the latent positions; the pair backward returns the latent-side gradient only
-        raise NotImplementedError("d/d(latent poses) through self-attention layers needs the pair kernel's query-side "
-                                  "gradient: not built (d/d a, d/d gaussian_window and d/d weights are)")
+    block on the hidden latents and the output MLP.  Differentiable w.r.t. the latents (poses included: the pair backward
+    also returns the query-side gradient, the queries of a self-attention block being the poses) and every weight."""
     n0 = _lib.ENF_NUM_TENSORS
     W = dict(zip(W_NAMES, tensors[:n0]))
     blk = W_NAMES[2:40]                                                    # the 38 tensors of one attention block
@@ -299,7 +361,7 @@ def apply_layers(model, tensors, x, p, a, sigma):
     sa = model.self_attn_invariant
     s = a @ W["stem_w"] + W["stem_b"]                                     # NEF:220
     view = _SelfAttnView(model)
-    xq = p[..., :sa.num_x_pos_dims].contiguous()                          # queries of a self-attention block: x = p
+    xq = p[..., :sa.num_x_pos_dims]                                       # queries of a self-attention block: x = p (differentiable)
     lay = lt_layout(view._desc(B, Z, Z))
     for i in range(model.num_layers):
         Wi = dict(zip(blk, tensors[n0 + 38 * i:n0 + 38 * (i + 1)]))

@@ -53,13 +53,8 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
         _, dp, da, dsig = nef.mse_value_and_latent_grads(nef_params, xs, _pose(lat, n_ori), lat["a"],
                                                          lat.get("gaussian_window"), ys_all[s])
         new = dict(lat)
-        if dp is None:          # models with self-attention layers have no pose gradient: the poses must be held fixed
-            if any(float(lrs[k].abs().max()) != 0.0 for k in ("p_pos", "p_ori") if k in lrs):
-                raise NotImplementedError("inner-loop pose updates need d/d(poses), which num_layers > 0 does not provide; "
-                                          "set inner_learning_rate_p = 0")
-        else:
-            new["p_pos"] = torch.addcmul(lat["p_pos"], dp[..., :n_pos], coef["p_pos"])
-        if n_ori > 0 and dp is not None:
+        new["p_pos"] = torch.addcmul(lat["p_pos"], dp[..., :n_pos], coef["p_pos"])
+        if n_ori > 0:
             new["p_ori"] = torch.addcmul(lat["p_ori"], dp[..., n_pos:], coef["p_ori"])
         new["a"] = torch.addcmul(lat["a"], da, coef["a"])
         if optimize_gaussian_window and dsig is not None:

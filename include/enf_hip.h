@@ -192,6 +192,12 @@ int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const 
 int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
                       const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
                       void* stream);
+/* The same with the gradient w.r.t. the QUERY coordinates (jax.grad of nef.apply w.r.t. x; the self-attention blocks of
+ * NEF:223-226 need it, their queries being the latent poses): `dx` (B,N,dx) fp32, ACCUMULATED into with float atomics
+ * (zero it first), or NULL. */
+int enf_pair_backward_ex(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                         const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
+                         float* dx, void* stream);
 
 /* Reconstruction loss of the inner loop and its gradient in one pass (pde_trainer.py:185):
  *   *loss += mean((out - target)^2)   (the caller zeroes *loss),   dout = 2 (out - target) / n * grad_scale  (dout may be NULL) */
