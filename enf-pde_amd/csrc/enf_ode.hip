@@ -11,6 +11,8 @@
 // d W = kb^T (g (x) a) over the pair axis is a plain GEMM and is left to the library (host side, like the decoder's
 // per-pair weight gradients).  The sum over the MFMA's K index is order-free, so each lane's four K-steps use four
 // CONSECUTIVE basis functions / channels (one 16-byte load feeds four MFMAs).
+// (First version: one wave per (b, r, channel tile) -- 8 re-reads of every basis tile and one dependent MFMA chain per
+// wave: 22.5 us per call at B=16, Z=64, J=64, C=128 = 0.31 of the fp32-MFMA peak.)
 #include <hip/hip_runtime.h>
 #include "enf_layout.h"
 
@@ -27,75 +29,105 @@ struct OdeConvArgs {
   long sR, sS;
 };
 
-// one wave per (b, r, 16-channel tile); the 4 waves of a block take 4 channel tiles
-template <int JM>   // J = 16 JM
+// One wave per (b, r) and group of CG 16-channel tiles; the 4 waves of a block take 4 receivers.  A sender tile's basis
+// values are loaded once and meet CG independent accumulators (the 16x16x4 f32 MFMA has a 40-cycle dependent latency
+// against a 32-cycle issue: independent chains keep the pipe full), W stays in registers for the whole sweep.
+template <int JM, int CG>   // J = 16 JM; CG channel tiles per wave (CG * JM * 4 <= 128 registers of W)
 __global__ __launch_bounds__(256) void enf_ode_conv_fwd_kernel(OdeConvArgs A) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, quad = lane >> 4;
-  const int ct = blockIdx.x * 4 + wave, r = blockIdx.y, b = blockIdx.z;
-  if (ct * 16 >= A.C) return;                                  // wave-uniform, no barrier follows
+  const int ct0 = blockIdx.x * CG, r = blockIdx.y * 4 + wave, b = blockIdx.z;
   const int C = A.C, J = A.J, Z = A.Z;
-  float wr[JM][4];                                             // A operand: W[16m + 4 quad + t][16 ct + col]
+  if (r >= Z) return;                                          // wave-uniform, no barrier follows
+  float wr[CG][JM][4];                                         // A operand: W[16m + 4 quad + t][16 ct + col]
 #pragma unroll
-  for (int m = 0; m < JM; ++m)
+  for (int g = 0; g < CG; ++g)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wr[m][t] = A.W[(size_t)(16 * m + 4 * quad + t) * C + 16 * ct + col];
+    for (int m = 0; m < JM; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        wr[g][m][t] = 16 * (ct0 + g) < C ? A.W[(size_t)(16 * m + 4 * quad + t) * C + 16 * (ct0 + g) + col] : 0.f;
   const float* kbr = A.kb + (size_t)b * Z * Z * J + (size_t)r * A.sR;
-  const float* ab = A.a + (size_t)b * Z * C + 16 * ct + 4 * quad;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* ab = A.a + (size_t)b * Z * C + 4 * quad;
+  f32x4 acc[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int s0 = 0; s0 < Z; s0 += 16) {
     const int s = s0 + col;
     const bool sv = s < Z;
     const float* kbs = kbr + (size_t)(sv ? s : 0) * A.sS + 4 * quad;
-    f32x4 d = {0.f, 0.f, 0.f, 0.f};                            // kernel[c = 16 ct + 4 quad + i][s]
+    f32x4 kv[JM];
 #pragma unroll
     for (int m = 0; m < JM; ++m) {
-      f32x4 kv = *reinterpret_cast<const f32x4*>(kbs + 16 * m);
-      if (!sv) kv = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m][t], kv[t], d, 0, 0, 0);
+      kv[m] = *reinterpret_cast<const f32x4*>(kbs + 16 * m);
+      if (!sv) kv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    f32x4 d[CG];                                               // kernel[c = 16 ct + 4 quad + i][s]
+#pragma unroll
+    for (int g = 0; g < CG; ++g) d[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < JM; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) d[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][m][t], kv[m][t], d[g], 0, 0, 0);
     if (sv) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(ab + (size_t)s * C);
-      acc += d * av;
+#pragma unroll
+      for (int g = 0; g < CG; ++g)
+        if (16 * (ct0 + g) < C) acc[g] += d[g] * *reinterpret_cast<const f32x4*>(ab + (size_t)s * C + 16 * (ct0 + g));
     }
   }
 #pragma unroll
-  for (int o = 1; o < 16; o <<= 1) {
+  for (int g = 0; g < CG; ++g) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
-  }
-  if (col == 0) {
-    if (A.bias) acc += *reinterpret_cast<const f32x4*>(A.bias + 16 * ct + 4 * quad);
-    *reinterpret_cast<f32x4*>(A.out + ((size_t)b * Z + r) * C + 16 * ct + 4 * quad) = acc;
+    for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[g][i] += __shfl_xor(acc[g][i], o, 64);
+    }
+    if (col == 0 && 16 * (ct0 + g) < C) {
+      if (A.bias) acc[g] += *reinterpret_cast<const f32x4*>(A.bias + 16 * (ct0 + g) + 4 * quad);
+      *reinterpret_cast<f32x4*>(A.out + ((size_t)b * Z + r) * C + 16 * (ct0 + g) + 4 * quad) = acc[g];
+    }
   }
 }
 
-// one wave per (b, r, 16-basis tile): d kb[b, r, s, 16 jt + 4 quad + i] for 16 senders at a time
-template <int CM>   // C = 16 CM
+// One wave per (b, r) and group of JG 16-basis tiles: d kb[b, r, s, 16 jt + 4 quad + i] for 16 senders at a time; the
+// product g (.) a of a sender tile is formed once and meets JG independent accumulators.
+template <int CM, int JG>   // C = 16 CM; JG basis tiles per wave (JG * CM * 4 <= 128 registers of W)
 __global__ __launch_bounds__(256) void enf_ode_conv_dkb_kernel(OdeConvArgs A) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, quad = lane >> 4;
-  const int jt = blockIdx.x * 4 + wave, r = blockIdx.y, b = blockIdx.z;
-  if (jt * 16 >= A.J) return;
+  const int jt0 = blockIdx.x * JG, r = blockIdx.y * 4 + wave, b = blockIdx.z;
   const int C = A.C, J = A.J, Z = A.Z;
-  f32x4 wr[CM], gr[CM];                                        // W[16 jt + col][16 m + 4 quad + t], g[b, r, 16 m + 4 quad + t]
+  if (r >= Z) return;
+  f32x4 wr[JG][CM], gr[CM];                                    // W[16 jt + col][16 m + 4 quad + t], g[b, r, 16 m + 4 quad + t]
 #pragma unroll
   for (int m = 0; m < CM; ++m) {
-    wr[m] = *reinterpret_cast<const f32x4*>(A.W + (size_t)(16 * jt + col) * C + 16 * m + 4 * quad);
     gr[m] = *reinterpret_cast<const f32x4*>(A.g + ((size_t)b * Z + r) * C + 16 * m + 4 * quad);
+#pragma unroll
+    for (int g = 0; g < JG; ++g)
+      wr[g][m] = 16 * (jt0 + g) < J ? *reinterpret_cast<const f32x4*>(A.W + (size_t)(16 * (jt0 + g) + col) * C + 16 * m + 4 * quad)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float* orow = A.out + ((size_t)b * Z + r) * Z * J + 16 * jt + 4 * quad;
+  float* orow = A.out + ((size_t)b * Z + r) * Z * J + 4 * quad;
   for (int s0 = 0; s0 < Z; s0 += 16) {
     const int s = s0 + col;
     const bool sv = s < Z;
     const float* as = A.a + ((size_t)b * Z + (sv ? s : 0)) * C + 4 * quad;
-    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[JG];
+#pragma unroll
+    for (int g = 0; g < JG; ++g) d[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < CM; ++m) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(as + 16 * m) * gr[m];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m][t], v[t], d, 0, 0, 0);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < JG; ++g) d[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][m][t], v[t], d[g], 0, 0, 0);
     }
-    if (sv) *reinterpret_cast<f32x4*>(orow + (size_t)s * J) = d;
+    if (sv) {
+#pragma unroll
+      for (int g = 0; g < JG; ++g)
+        if (16 * (jt0 + g) < J) *reinterpret_cast<f32x4*>(orow + (size_t)s * J + 16 * (jt0 + g)) = d[g];
+    }
   }
 }
 
@@ -115,14 +147,19 @@ extern "C" int enf_ode_conv_forward(int B, int Z, int J, int C, const float* a, 
   if (!a || !kb || !W || !out) return ENF_EINVAL;
   if (kb_stride_r % 4 || kb_stride_s % 4) return ENF_EINVAL;  // 16-byte loads along the basis axis
   OdeConvArgs A{a, kb, W, bias, nullptr, out, B, Z, J, C, (long)kb_stride_r, (long)kb_stride_s};
-  const dim3 grid((C / 16 + 3) / 4, Z, B), block(256);
+  // channel tiles per wave: all of them while W fits 128 registers, fewer (more waves) when B Z alone cannot fill the chip
+  const int CT = C / 16, JM = J / 16;
+  int cg = CT;
+  while (cg * JM * 4 > 128) cg /= 2;
+  while (cg > 1 && (long)B * Z * (CT / cg) < 2048) cg /= 2;
+  const dim3 grid(CT / cg, (Z + 3) / 4, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  switch (J / 16) {
-    case 1: hipLaunchKernelGGL(enf_ode_conv_fwd_kernel<1>, grid, block, 0, st, A); break;
-    case 2: hipLaunchKernelGGL(enf_ode_conv_fwd_kernel<2>, grid, block, 0, st, A); break;
-    case 4: hipLaunchKernelGGL(enf_ode_conv_fwd_kernel<4>, grid, block, 0, st, A); break;
-    default: hipLaunchKernelGGL(enf_ode_conv_fwd_kernel<8>, grid, block, 0, st, A); break;
-  }
+#define ODE_FWD(JM_, CG_) if (JM == JM_ && cg == CG_) hipLaunchKernelGGL((enf_ode_conv_fwd_kernel<JM_, CG_>), grid, block, 0, st, A);
+  ODE_FWD(1, 1) ODE_FWD(1, 2) ODE_FWD(1, 4) ODE_FWD(1, 8)
+  ODE_FWD(2, 1) ODE_FWD(2, 2) ODE_FWD(2, 4) ODE_FWD(2, 8)
+  ODE_FWD(4, 1) ODE_FWD(4, 2) ODE_FWD(4, 4) ODE_FWD(4, 8)
+  ODE_FWD(8, 1) ODE_FWD(8, 2) ODE_FWD(8, 4)
+#undef ODE_FWD
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
 
@@ -132,13 +169,17 @@ extern "C" int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const flo
   if (rc) return rc;
   if (!a || !g || !W || !dkb) return ENF_EINVAL;
   OdeConvArgs A{a, nullptr, W, nullptr, g, dkb, B, Z, J, C, 0, 0};
-  const dim3 grid((J / 16 + 3) / 4, Z, B), block(256);
+  const int CM = C / 16, JT = J / 16;
+  int jg = JT;
+  while (jg * CM * 4 > 128) jg /= 2;
+  while (jg > 1 && (long)B * Z * (JT / jg) < 2048) jg /= 2;
+  const dim3 grid(JT / jg, (Z + 3) / 4, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  switch (C / 16) {
-    case 1: hipLaunchKernelGGL(enf_ode_conv_dkb_kernel<1>, grid, block, 0, st, A); break;
-    case 2: hipLaunchKernelGGL(enf_ode_conv_dkb_kernel<2>, grid, block, 0, st, A); break;
-    case 4: hipLaunchKernelGGL(enf_ode_conv_dkb_kernel<4>, grid, block, 0, st, A); break;
-    default: hipLaunchKernelGGL(enf_ode_conv_dkb_kernel<8>, grid, block, 0, st, A); break;
-  }
+#define ODE_DKB(CM_, JG_) if (CM == CM_ && jg == JG_) hipLaunchKernelGGL((enf_ode_conv_dkb_kernel<CM_, JG_>), grid, block, 0, st, A);
+  ODE_DKB(1, 1) ODE_DKB(1, 2) ODE_DKB(1, 4) ODE_DKB(1, 8)
+  ODE_DKB(2, 1) ODE_DKB(2, 2) ODE_DKB(2, 4) ODE_DKB(2, 8)
+  ODE_DKB(4, 1) ODE_DKB(4, 2) ODE_DKB(4, 4) ODE_DKB(4, 8)
+  ODE_DKB(8, 1) ODE_DKB(8, 2) ODE_DKB(8, 4)
+#undef ODE_DKB
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
