@@ -16,8 +16,9 @@ adjoint recursion over the inner steps
     g_alpha  -= sum lambda_{s+1} * g_s
 
 whose only second-order objects are Hessian(-mixed)-vector products along ONE direction w per step.
-``second_order="fd"`` evaluates them by central differences of first-order gradients at phi_s +- eps w (two
-extra forward+backward passes with weight gradients per inner step; ``fd_step`` = the largest component of the
+``second_order="fd"`` evaluates them by central differences of first-order gradients at phi_s +- eps w (one extra
+training-path pass per inner step over a batch of 2B signals: the +eps and -eps latent sets side by side, the second
+half entering the loss negated, so that the pass returns the difference of the two gradients; ``fd_step`` = the largest component of the
 perturbation); ``second_order="none"`` drops them (first-order MAML).
 
 Accuracy against exact double-backward of the oracle (scripts/meta_grad_err.py, tests/test_gpu_trainer.py; f32
@@ -93,6 +94,24 @@ def _full_grads(nef, weights, coords, img, masks, s, lat, keys):
     return loss.detach(), gw, gl
 
 
+def _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys):
+    """grads(plus) - grads(minus) of the step-s loss, w.r.t. the weights and the latents, in ONE training-path pass: the two
+    latent sets run as one batch of 2B signals whose second half enters the loss with a minus sign (the outer step is
+    launch-bound, so one pass of twice the batch costs about half of two passes)."""
+    B = img.shape[0]
+    w = [t.detach().requires_grad_(True) for t in weights]
+    leaves = {k: torch.cat([plus[k], minus[k]], 0).detach().requires_grad_(True) for k in plus}
+    n_ori = nef.cross_attn_invariant.num_z_ori_dims
+    xs = coords[masks[:, s]][None].expand(2 * B, -1, -1)
+    ys = img[:, masks[:, s]]
+    out = nef.apply(_tree_from_tensors(w), xs, _pose(leaves, n_ori), leaves["a"], leaves.get("gaussian_window"))
+    loss = ((out[:B] - ys) ** 2).mean() - ((out[B:] - ys) ** 2).mean()
+    g = torch.autograd.grad(loss, w + [leaves[k] for k in keys], allow_unused=True)
+    gw = [torch.zeros_like(t) if gi is None else gi for t, gi in zip(w, g[:len(w)])]
+    gl = {k: (torch.zeros_like(plus[k]) if gi is None else gi[:B] + gi[B:]) for k, gi in zip(keys, g[len(w):])}
+    return gw, gl
+
+
 def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaussian_window=False,
                    second_order="fd", fd_step=2e-2, noise_pos=0.0, generator=None, terminal=None):
     """Value and gradient of the last-inner-step loss w.r.t. (nef weights, meta-init latents, inner lrs).
@@ -147,11 +166,10 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
         eps = fd_step / wmax
         plus = {k: phis[s][k] + eps * w[k] for k in lam}
         minus = {k: phis[s][k] - eps * w[k] for k in lam}
-        _, gw_p, gl_p = _full_grads(nef, weights, coords, img, masks, s, plus, keys)
-        _, gw_m, gl_m = _full_grads(nef, weights, coords, img, masks, s, minus, keys)
+        gw_d, gl_d = _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys)
         c = B / (2.0 * eps)
-        g_theta = [gt - c * (a - b) for gt, a, b in zip(g_theta, gw_p, gw_m)]
-        lam = {k: lam[k] - c * (gl_p.get(k, 0) - gl_m.get(k, 0)) if k in gl_p else lam[k] for k in lam}
+        g_theta = list(torch._foreach_add(g_theta, gw_d, alpha=-c))
+        lam = {k: lam[k] - c * gl_d[k] if k in gl_d else lam[k] for k in lam}
     g_lat0 = {k: lam[k].sum(dim=0, keepdim=True) for k in lam}
     return loss, {"nef": g_theta, "autodecoder": g_lat0, "meta_sgd_lrs": g_alpha}
 
