@@ -11,11 +11,15 @@
 // A-fragment order and c_zh as fp32 vectors.  2 D^3 FLOP per (latent, head): 8.6 GFLOP for 1024 latents,
 // against 2 TFLOP of per-pair work it feeds.
 //
-// One wave = one (latent, head, 32-row block of W).  The product runs "flipped" (gemm_tile_flip): rows of
+// One wave = one (head, 32-row block of W) for a strided set of latents: everything that does not depend on the latent --
+// the Wgamma rows, the Wbeta AM tiles the accumulators start from -- is loaded ONCE into registers and reused (the first
+// version re-read them per latent: 57 KB of L2 traffic per (latent, head, block) task, 470 MB per call, which bound it).
+// The product runs "flipped" (gemm_tile_flip): rows of
 // W (the GEMM's input features i) play the role of activation columns, so the accumulator tile of
 // (i-tile, k-tile) holds, lane by lane, exactly the elements of that lane's A-fragment (k-tile, i-block):
 // the result is converted and stored 16 bytes per lane, lane-linear, no transpose.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "enf_layout.h"
 #include "enf_device.h"
 
@@ -29,7 +33,7 @@ struct WzArgs {
 
 constexpr int WZ_WAVES = 4;
 #ifndef ENF_WZ_MAXGRID
-#define ENF_WZ_MAXGRID 1024
+#define ENF_WZ_MAXGRID 256      // x 4 waves = one per SIMD (the bf16 128-wide instantiation holds 352 registers)
 #endif
 
 template <int D, int H, bool BF16>
@@ -47,26 +51,48 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(A.blob + off); };
   const float* agb = G(A.L.p_agb);
   const int ltstride = enf_lt_stride(H, D);
-  const int ntask = A.BZ * H * KB;
-  for (int task = blockIdx.x * WZ_WAVES + wave; task < ntask; task += gridDim.x * WZ_WAVES) {
-    const int blk = task % KB, h = (task / KB) % H, bz = task / (KB * H);
+  // (gridDim.x * WZ_WAVES is a multiple of H * KB: launch_wz)
+  constexpr int COMBOS = H * KB;
+  const int gw = blockIdx.x * WZ_WAVES + wave, lat_stride = gridDim.x * WZ_WAVES / COMBOS;
+  const int blk = (gw % COMBOS) % KB, h = (gw % COMBOS) / KB;
+  // latent-independent operands of this (head, block), resident for the whole sweep
+  f32x4 wg[2][NT], bf[2][NT];
+  const float* wbmt = G(A.L.p_wbmt) + (size_t)h * D * D;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float* row = agb + (size_t)(16 * (2 * blk + a) + col) * (2 * H * D) + h * 2 * D;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      wg[a][tj] = *reinterpret_cast<const f32x4*>(row + 64 * (tj >> 1) + 16 * (tj & 1) + 4 * quad);
+      bf[a][tj] = *reinterpret_cast<const f32x4*>(wbmt + (size_t)(16 * tj + col) * D + 16 * (2 * blk + a) + 4 * quad);
+    }
+  }
+  f32x4 bb[2][NT];                                               // backward orientation: Wbeta AM tiles, un-flipped
+  if (A.wzt) {
+    const float* wbm = G(A.L.p_wbm) + (size_t)h * D * D;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+        bb[a][kt] = *reinterpret_cast<const f32x4*>(wbm + (size_t)(16 * (2 * blk + a) + col) * D + 16 * kt + 4 * quad);
+  }
+  for (int bz = gw / COMBOS; bz < A.BZ; bz += lat_stride) {
     const float* v0 = A.lt + (size_t)bz * ltstride + enf_lt_off_v0(H, D) + h * D;
     // "activation" fragments: X[i][j] = Wgamma_h[i][j] v0[j], rows i = 16 (2 blk + a) + col as columns
     Frags<BF16, KB> FX[2];
+    {
+      f32x4 v[NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const float* row = agb + (size_t)(16 * (2 * blk + a) + col) * (2 * H * D) + h * 2 * D;
-      f32x4 X[NT];
+      for (int tj = 0; tj < NT; ++tj) v[tj] = *reinterpret_cast<const f32x4*>(v0 + 16 * tj + 4 * quad);
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(row + 64 * (tj >> 1) + 16 * (tj & 1) + 4 * quad);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(v0 + 16 * tj + 4 * quad);
-        X[tj] = w * v;
+      for (int a = 0; a < 2; ++a) {
+        f32x4 X[NT];
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) X[tj] = wg[a][tj] * v[tj];
+        make_frags<BF16, KB>(FX[a], X);
       }
-      make_frags<BF16, KB>(FX[a], X);
     }
     char* panel = A.wz + (size_t)(bz * H + h) * A.pstride;
-    const float* wbmt = G(A.L.p_wbmt) + (size_t)h * D * D;
     {
       // forward orientation: flipped product of all NT k-tiles for the two i-tiles of this block (hand-scheduled
       // stage when available), then lane-linear fragment stores
@@ -74,8 +100,7 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-          af[a][kt] = *reinterpret_cast<const f32x4*>(wbmt + (size_t)(16 * kt + col) * D + 16 * (2 * blk + a) + 4 * quad);
+        for (int kt = 0; kt < NT; ++kt) af[a][kt] = bf[a][kt];
         if constexpr (BF16 && ENF_ASM_GEMM && GemmStageAsm<KB, NT>::available) {
           GemmStageAsm<KB, NT>::run_flip(af[a], FX[a].f, (unsigned)(uintptr_t)(lds_ptr_t)(smem + (lane << 4)));
         } else {
@@ -102,13 +127,12 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
       // the un-flipped product puts (k-tile, i-columns) tiles in the accumulators, whose lanes hold exactly the
       // elements of fragment (mt = i-tile, blk = k-block)
       char* panel_t = A.wzt + (size_t)(bz * H + h) * A.pstride;
-      const float* wbm = G(A.L.p_wbm) + (size_t)h * D * D;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int it = 2 * blk + a;
         f32x4 acc[NT];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) acc[kt] = *reinterpret_cast<const f32x4*>(wbm + (size_t)(16 * it + col) * D + 16 * kt + 4 * quad);
+        for (int kt = 0; kt < NT; ++kt) acc[kt] = bb[a][kt];
         gemm_stage<BF16, KB, NT>(acc, FX[a], smem, lane);
         if constexpr (BF16) {
 #pragma unroll
@@ -171,9 +195,15 @@ static int launch_wz(const WzArgs& A, hipStream_t st) {
       return ENF_ELAUNCH;
     attr_set = true;
   }
-  const int ntask = A.BZ * H * (D / 32);
-  int grid = (ntask + WZ_WAVES - 1) / WZ_WAVES;
-  if (grid > ENF_WZ_MAXGRID) grid = ENF_WZ_MAXGRID;
+  // waves = COMBOS (head, block) roles x a number of latent lanes; each wave sweeps BZ / lanes latents
+  constexpr int COMBOS = H * (D / 32);
+  static int maxgrid = 0;
+  if (!maxgrid) { const char* e = getenv("ENF_WZ_GRID"); maxgrid = e ? atoi(e) : ENF_WZ_MAXGRID; if (maxgrid < 2) maxgrid = 2; }
+  const int max_waves = maxgrid * WZ_WAVES;
+  int lanes = A.BZ;
+  while (lanes * COMBOS > max_waves && lanes > 1) lanes = (lanes + 1) / 2;
+  int grid = (lanes * COMBOS + WZ_WAVES - 1) / WZ_WAVES;
+  while ((grid * WZ_WAVES) % COMBOS) ++grid;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WZ_WAVES), PB, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
