@@ -245,6 +245,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        torch.distributed.barrier()          # ranks leave together (rank 0 has just run its extra legs)
         torch.distributed.destroy_process_group()
 
 
