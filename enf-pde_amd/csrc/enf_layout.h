@@ -186,6 +186,9 @@ ENF_HD inline int enf_lt_off_c(int H, int D) { return 2 * H * D + 8; }
 // ENF_ZFOLD=0 / 1 in the environment, or enf_set_zfold(), forces the choice (tests).
 int enf_zfold_mode();   // enf_api.hip: -1 heuristic, 0 / 1 forced (ENF_ZFOLD in the environment, or enf_set_zfold)
 inline bool enf_use_zfold(const EnfDims& m) {
+  // one signal's folded matrices sit behind a buffer resource with 32-bit offsets: beyond 2 GB per signal (Z >= 32768
+  // at D = 128, H = 2) only the latent-split variant can run
+  if ((long long)m.Z * m.H * (long long)m.D * m.D * (m.bf16 ? 2 : 4) >= 0x7fffffffLL) return false;
   const int mode = enf_zfold_mode();
   if (mode >= 0) return mode == 1;
   return (long long)((m.N + 127) / 128) * m.B >= 192;
