@@ -1,0 +1,74 @@
+"""Two ranks on one GPU (gloo, so both may share the card): the outer steps of the trainer exchange exactly one flat
+all-reduce and leave every rank with identical parameters -- nef_train_step and ode_train_step, each rank
+on its own shard of the meta-batch; the result equals a single process that averages the two shards' gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from enf_pde_amd.fitting import init_distributed, shard_range
+    from tests.test_gpu_ode_trainer import _setup
+    from tests.test_gpu_ode import _flat
+    init_distributed(backend="gloo")
+    cuda = torch.device("cuda:0")
+    cfg, prm, ocfg, oprm, coords, traj, conf, tr, state, t = _setup(cuda)
+    batch = t(traj)                                              # 2 trajectories: one per rank
+    lo, hi = shard_range(batch.shape[0], rank, world)
+    mk = torch.stack([torch.randperm(64, generator=torch.Generator().manual_seed(1))[:32] for _ in range(3)], 1).to(cuda)
+    pm = torch.stack([torch.randperm(64, generator=torch.Generator().manual_seed(2))[:32] for _ in range(3)]).to(cuda)
+    l1, s1 = tr.nef_train_step(state, batch[lo:hi, 0], masks=mk)
+    l2, s2 = tr.ode_train_step(s1, batch[lo:hi], masks=mk, point_masks=pm)
+    w = torch.cat([x.reshape(-1) for x in tr.nef.param_tensors(s2.params["nef"])]).cpu()
+    o = torch.cat([v.reshape(-1) for _, v in _flat(s2.params["ode_params"])]).cpu()
+    q.put((rank, float(l1), float(l2), w.numpy(), o.numpy()))       # plain arrays: no shared-memory handles to outlive us
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_outer_step(cuda):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, a1, a2, wa, oa), (_, b1, b2, wb, ob) = [(r, x, y, torch.from_numpy(w_), torch.from_numpy(o_)) for r, x, y, w_, o_ in res]
+    assert a1 == b1 and a2 == b2                                 # the reported loss is the all-reduced mean
+    assert torch.equal(wa, wb) and torch.equal(oa, ob)           # identical updates on every rank
+    # the single-process step on the whole batch: same nef update (per-signal losses average the same way)
+    from tests.test_gpu_ode_trainer import _setup
+    from tests.test_gpu_ode import _flat
+    cfg, prm, ocfg, oprm, coords, traj, conf, tr, state, t = _setup(cuda)
+    batch = t(traj)
+    mk = torch.stack([torch.randperm(64, generator=torch.Generator().manual_seed(1))[:32] for _ in range(3)], 1).to(cuda)
+    pm = torch.stack([torch.randperm(64, generator=torch.Generator().manual_seed(2))[:32] for _ in range(3)]).to(cuda)
+    l1, s1 = tr.nef_train_step(state, batch[:, 0], masks=mk)
+    l2, s2 = tr.ode_train_step(s1, batch, masks=mk, point_masks=pm)
+    w = torch.cat([x.reshape(-1) for x in tr.nef.param_tensors(s2.params["nef"])]).cpu()
+    o = torch.cat([v.reshape(-1) for _, v in _flat(s2.params["ode_params"])]).cpu()
+    assert abs(float(l1) - a1) < 1e-4 * abs(a1) and abs(float(l2) - a2) < 1e-3 * abs(a2)
+    # the first Adam step is lr * sign-ish(g): entries whose gradient is within rounding / finite-difference noise of zero
+    # (the step size of the Hessian-vector differences is chosen per batch) may move the other way; the rest agree
+    assert ((w - wa).abs() < 2e-4).float().mean() > 0.97 and ((o - oa).abs() < 2e-4).float().mean() > 0.97
