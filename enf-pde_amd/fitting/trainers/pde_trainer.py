@@ -290,11 +290,22 @@ class MetaSGDPDETrainer:
                                generator=state.rng, device=coords.device)
         return coords, img, masks
 
-    def rollout(self, ode_params, lat, num_frames):
-        """Latents of ``num_frames`` frames from the fitted ones: (B, T, Z, .) each (pde_trainer.py:432-441)."""
+    def rollout(self, ode_params, lat, num_frames, graph=False):
+        """Latents of ``num_frames`` frames from the fitted ones: (B, T, Z, .) each (pde_trainer.py:432-441).
+        graph=True (inference): every derivative evaluation replays one captured hipGraph (PonitaODEGen.graphed)."""
         cfg = self.config
         n_ori = self.nef.cross_attn_invariant.num_z_ori_dims
         z0 = (_pose(lat, n_ori), lat["a"], lat.get("gaussian_window"))
+        if graph and hasattr(self.ode_model, "graphed") and not torch.is_grad_enabled():
+            # one capture per (parameter tensors, latent shapes): validation sweeps many batches with the same parameters
+            leaves = _leaves(ode_params)
+            key = (tuple(id(t) for t in leaves), tuple(None if v is None else tuple(v.shape) for v in z0))
+            hit = getattr(self, "_ode_graph", None)
+            if hit is None or hit[0] != key:
+                hit = (key, self.ode_model.graphed(ode_params, z0), leaves)      # (leaves kept alive: ids stay unique)
+                self._ode_graph = hit
+            f = hit[1]
+            return solve_latent_ode(lambda z, t: f(z), z0, 0, num_frames - 1, cfg.node.dt, method=cfg.node.method)
         return solve_latent_ode(lambda z, t: self.ode_model.apply(ode_params, z), z0, 0, num_frames - 1, cfg.node.dt,
                                 method=cfg.node.method)
 
@@ -437,7 +448,7 @@ class MetaSGDPDETrainer:
         with torch.enable_grad():
             _, lat = inner_loop(self.nef, state.params["nef"], self._latents0(state), state.params["meta_sgd_lrs"], coords, img, masks,
                                 optimize_gaussian_window=getattr(cfg.nef, "optimize_gaussian_window", False))
-        sol = self.rollout(state.params["ode_params"], {k: v.detach() for k, v in lat.items()}, T)
+        sol = self.rollout(state.params["ode_params"], {k: v.detach() for k, v in lat.items()}, T, graph=T > 4)
         p_fl, a_fl, w_fl = (None if v is None else v.reshape(B * T, *v.shape[2:]) for v in sol)
         recon = decode(self.nef, state.params["nef"], self.coords, p_fl, a_fl, w_fl).reshape(trajectory.shape)
         err = (recon - trajectory) ** 2

@@ -134,6 +134,24 @@ def test_rollout_matches_oracle(cuda, method):
     assert np.abs(ref[1][:, -1] - ref[1][:, 0]).max() > 1e-3          # the latents do move
 
 
+def test_graphed_derivative_replays_bitwise(cuda):
+    """PonitaODEGen.graphed: one captured hipGraph per derivative evaluation gives the same roll-out as eager launches."""
+    from enf_pde_amd.fitting.trainers.trainer_utils import solve_latent_ode
+    cfg = ode_cfg("rel_pos_periodic", num_hidden=64, basis_dim=32, num_layers=3)
+    prm = O.init_ponita_ode(9, cfg, latent_dim=8, jitter=0.1, readout_scale=0.05)
+    model = _model(cfg, 8)
+    P = model.load_params(prm, device=cuda)
+    dl = tuple(torch.tensor(v, dtype=torch.float32, device=cuda) for v in ode_inputs(cfg, 3, 16, 8, 10))
+    with torch.no_grad():
+        f = model.graphed(P, dl)
+        eager = solve_latent_ode(lambda z, t: model.apply(P, z), dl, 0, 6, 1, method="rk4")
+        graph = solve_latent_ode(lambda z, t: f(z), dl, 0, 6, 1, method="rk4")
+    assert all(torch.equal(g, e) for g, e in zip(graph, eager))
+    P["params"]["ponita"]["readout_scalar"]["layers_0"]["kernel"].mul_(2.0)        # parameters are read in place
+    with torch.no_grad():
+        assert torch.equal(f(dl)[1], model.apply(P, dl)[1])
+
+
 def test_rollout_gradient_reaches_the_ode_weights(cuda):
     """ode_loss (pde_trainer.py:411-500) differentiates a roll-out w.r.t. the ODE parameters."""
     from enf_pde_amd.fitting.trainers.trainer_utils import solve_latent_ode
