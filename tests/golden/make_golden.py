@@ -87,7 +87,43 @@ def make_inner_loop():
     return rec
 
 
+# latent-ODE fixtures: name -> (ode cfg kwargs, B, Z, latent_dim, param seed)
+ODE_CASES = {
+    "ode_rel_pos_periodic": (dict(invariant="rel_pos_periodic", num_hidden=32, basis_dim=16, num_layers=2), 2, 6, 8, 31),
+    "ode_ponita": (dict(invariant="ponita", num_hidden=16, basis_dim=16, num_layers=3, kernel_size=0.2), 2, 5, 4, 32),
+}
+
+
+def make_ode_case(name):
+    """PonitaODEGen derivative, its gradients for a fixed cotangent, and 4-step Euler / RK4 roll-outs (fp64 oracle)."""
+    from oracle import ode_ref_np as O
+    from oracle import ode_ref_torch as OT
+    from tests.test_ode_oracle import ode_cfg, ode_inputs
+    kw, B, Z, C, seed = ODE_CASES[name]
+    cfg = ode_cfg(kw["invariant"], **{k: v for k, v in kw.items() if k != "invariant"})
+    prm = O.init_ponita_ode(seed, cfg, latent_dim=C, jitter=0.1, readout_scale=0.05)
+    p, a, w = ode_inputs(cfg, B, Z, C, seed + 100)
+    rng = np.random.default_rng(seed + 200)
+    wp, wa = rng.standard_normal(p.shape), rng.standard_normal(a.shape)
+    dp, da, _ = O.ponita_ode(prm, cfg, (p, a, w))
+    tp = T.to_torch(prm, torch.float64)
+    tpp, ta = torch.tensor(p, requires_grad=True), torch.tensor(a, requires_grad=True)
+    odp, oda, _ = OT.ponita_ode(tp, cfg, (tpp, ta, torch.tensor(w)))
+    ((odp * torch.tensor(wp)).sum() + (oda * torch.tensor(wa)).sum()).backward()
+    assert np.abs(odp.detach().numpy() - dp).max() < 1e-10
+    rec = dict(p=p, a=a, window=w, wp=wp, wa=wa, dp=dp, da=da, gp=tpp.grad.numpy(), ga=ta.grad.numpy(),
+               param_seed=np.int64(seed), jitter=np.float64(0.1), readout_scale=np.float64(0.05))
+    for method in ("euler", "rk4"):
+        tr = O.solve_latent_ode(lambda z, t: O.ponita_ode(prm, cfg, z), (p, a, w), 0, 4, 1, method=method)
+        rec[method + "/p"], rec[method + "/a"] = tr[0], tr[1]
+    return cfg, rec
+
+
 if __name__ == "__main__":
+    for name in ODE_CASES:
+        cfg, rec = make_ode_case(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+        print(name, {k: v.shape for k, v in rec.items() if hasattr(v, "shape")})
     for name in CASES:
         cfg, rec = make_case(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)

@@ -140,3 +140,13 @@ def test_solvers_on_a_linear_system():
     ft = lambda x, t: (-x[0], 2.0 * x[1], torch.zeros_like(x[2]))
     tr = OT.solve_latent_ode(ft, tuple(torch.tensor(v) for v in x0), 0, 4, 0.5, method="rk4")
     assert np.allclose(tr[0].numpy(), pr) and np.allclose(tr[1].numpy(), ar)
+
+
+@pytest.mark.parametrize("name", ["ode_rel_pos_periodic", "ode_ponita"])
+def test_oracle_reproduces_ode_golden(name):
+    import os
+    from tests.golden.make_golden import make_ode_case
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    _, rec = make_ode_case(name)
+    for k in g.files:
+        assert np.allclose(np.asarray(rec[k]), g[k], rtol=1e-9, atol=1e-12), (name, k)
