@@ -26,6 +26,8 @@ CASES = {
     "tiny_polar_periodic": (dict(invariant="polar_periodic", D=64, H=2, C=4, O=1, freq=(0.5, 0.5)), 2, 11, 6, 13, False),
     "tiny_latitude_periodic": (dict(invariant="latitude_periodic", D=64, H=2, C=8, O=3, freq=(0.05, 0.2)), 1, 13, 8, 14, False),
     "cfg2_rel_pos_periodic": (dict(invariant="rel_pos_periodic", D=128, H=2, C=16, O=1), 2, 64, 64, 15, False),
+    "tiny_ball": (dict(invariant="ball", D=64, H=2, C=8, O=1, freq=(0.2, 0.5)), 2, 9, 5, 16, False),          # config_ihc.yaml's invariant
+    "tiny_ball_lat": (dict(invariant="ball_lat", D=64, H=1, C=8, O=2, freq=(0.2, 0.5)), 2, 7, 4, 17, False),
 }
 
 
