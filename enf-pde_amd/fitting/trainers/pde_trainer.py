@@ -25,9 +25,12 @@ Accuracy against exact double-backward of the oracle (scripts/meta_grad_err.py, 
 mode): first-order MAML is off by 7-50 % per tensor on the test problems -- the second-order terms matter; the
 finite-difference form brings 42 of the 46 weight tensors, the latent features and the inner learning rates to
 ~1e-3..1e-2.  The four tensors feeding a relu (layers_0 kernel/bias of the two RFFNets) and the position
-initialisation stay at 2-20 %: a finite perturbation flips relu masks, which automatic differentiation (the
-reference's jax.grad, and the oracle) never sees; the flips act as noise that shrinks with more pairs and a larger
-step.  An exact a.e. second-order term needs tangent-mode (JVP) pair kernels -- not built.
+initialisation stay at 2-20 %, and their error GROWS as the step shrinks (22 % at 2e-2, 32 % at 5e-3, 95 % at 1e-3 on
+the first test problem): the differences are dominated by fp32 rounding of the first-order gradients there.  Relu masks
+flipping under the finite perturbation were the suspected cause and are NOT it: an experiment that recorded the masks at
+phi_s in K2 and replayed them in both perturbed passes (relu linearised at phi_s, forward and K3) left these errors
+unchanged (0.22 -> 0.22, 0.093 -> 0.093; the other tensors moved from 7.7e-3 to 6.2e-3) and was removed again.  An exact
+a.e. second-order term needs tangent-mode (JVP) pair kernels -- not built.
 """
 import math
 from dataclasses import dataclass, field

@@ -67,7 +67,7 @@ def test_meta_gradient_fd_matches_exact_second_order(cuda):
     for path, a, b in zip(TENSOR_PATHS, g["nef"], gw_r):
         nb = np.linalg.norm(b)
         e = np.linalg.norm(a.cpu().numpy() - b) / (nb if nb > 1e-3 * gmax else gmax)
-        # tensors feeding a relu see mask flips under a finite perturbation (see pde_trainer.py docstring)
+        # the four relu-adjacent tensors are the ill-conditioned ones of the finite-difference form (pde_trainer.py docstring)
         tol = 0.3 if path[-3:-1] == ("layers_0", "linear") else 2e-2
         if not e < tol:
             bad.append(("/".join(path[-3:]), e))
