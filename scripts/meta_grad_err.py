@@ -13,7 +13,7 @@ for kw in (dict(), dict(B=8, Ns=64, side=8, Z=16)):
     nef = build_nef(cfg, "f32"); params = nef.load_params(prm, device=cuda)
     t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
     res = {}
-    for mode, step in (("none", 0), ("fd", 5e-3), ("fd", 2e-2), ("fd", 1e-3)):
+    for mode, step in (("none", 0), ("fd", 2e-2), ("fd", 5e-2), ("fd", 1e-1), ("fd", 3e-1)):
         _, g = meta_gradients(nef, params, {k: t(v) for k, v in lat0.items()}, {k: t(v) for k, v in lrs.items()}, t(coords), t(img),
                               torch.tensor(masks, device=cuda), second_order=mode, fd_step=step or 5e-3)
         res[(mode, step)] = g
