@@ -25,8 +25,9 @@ Accuracy against exact double-backward of the oracle (scripts/meta_grad_err.py, 
 mode): first-order MAML is off by 7-50 % per tensor on the test problems -- the second-order terms matter; the
 finite-difference form brings 42 of the 46 weight tensors, the latent features and the inner learning rates to
 ~1e-3..1e-2.  The four tensors feeding a relu (layers_0 kernel/bias of the two RFFNets) and the position
-initialisation stay at 2-20 %, and their error GROWS as the step shrinks (22 % at 2e-2, 32 % at 5e-3, 95 % at 1e-3 on
-the first test problem): the differences are dominated by fp32 rounding of the first-order gradients there.  Relu masks
+initialisation stay at 2-20 %; their error is U-shaped in the step (95 % at 1e-3, 32 % at 5e-3, 22 % at 2e-2, 10 % at
+1e-1, 13 % at 3e-1 on the first test problem; the other tensors are best at 2e-2 and reach 2 % at 1e-1): noise of the
+first-order gradients on one side, truncation on the other, with a floor near 10 %.  Relu masks
 flipping under the finite perturbation were the suspected cause and are NOT it: an experiment that recorded the masks at
 phi_s in K2 and replayed them in both perturbed passes (relu linearised at phi_s, forward and K3) left these errors
 unchanged (0.22 -> 0.22, 0.093 -> 0.093; the other tensors moved from 7.7e-3 to 6.2e-3) and was removed again.  An exact
