@@ -243,6 +243,19 @@ extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstr
                              (hipStream_t)stream);
 }
 
+extern "C" void enf_pair_fwd_set_masks(unsigned* masks, int mode, int mask_B);
+extern "C" void enf_pair_bwd_set_masks(const unsigned* masks, int mask_B);
+extern "C" size_t enf_relu_mask_bytes(const EnfDesc* d) {
+  if (enf_check_desc(d) != ENF_OK) return 0;
+  return (size_t)d->B * d->Z * ((d->N + 15) / 16) * 2 * 64 * sizeof(unsigned);
+}
+extern "C" int enf_set_relu_masks(void* masks, int mode, int mask_signals) {
+  if (mode < 0 || mode > 2 || (mode && !masks)) return ENF_EINVAL;
+  enf_pair_fwd_set_masks(mode ? (unsigned*)masks : nullptr, mode, mask_signals);
+  enf_pair_bwd_set_masks(mode == 2 ? (const unsigned*)masks : nullptr, mask_signals);
+  return ENF_OK;
+}
+
 extern "C" int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
                                  const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
                                  void* stream) {

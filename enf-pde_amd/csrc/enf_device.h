@@ -103,6 +103,30 @@ template <bool BF16, int KB> DEV void relu_frags(Frags<BF16, KB>& F) {
   }
 }
 
+// relu masks (enf_hip.h: ENF_MASK_*): one 32-bit word per lane, pair tile and relu layer; bit (4 t + i) = pre-activation
+// [t][i] > 0.  relu_mask_of builds it; relu_apply_mask is the relu LINEARISED at the point the mask was taken
+// (h = a where the bit is set, 0 elsewhere -- NOT max(a, 0)), which is what a finite difference of gradients needs
+// to equal the almost-everywhere second derivative (relu'' = 0) instead of also counting the units that flip.
+template <int NT> DEV unsigned relu_mask_of(const f32x4 (&X)[NT]) {
+  static_assert(NT <= 8, "32 bits per lane");
+  unsigned m = 0u;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m |= X[t][i] > 0.f ? 1u << (4 * t + i) : 0u;
+  return m;
+}
+template <int NT> DEV void relu_apply_mask(f32x4 (&X)[NT], unsigned m) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[t][i] = (m >> (4 * t + i)) & 1u ? X[t][i] : 0.f;
+}
+// word index of (signal b, latent z, 16-query tile, layer 0 = query RFFNet / 1 = value RFFNet, lane)
+DEV size_t relu_mask_index(int b, int Z, int z, int ntiles, int tile, int layer, int lane) {
+  return ((((size_t)b * Z + z) * ntiles + tile) * 2 + layer) * 64 + lane;
+}
+
 // acc[mt] += W^T[16 mt .., :] X for MTS out-tiles whose fragments start at `lds`.
 // Panel order (enf_pack.hip): bf16 [mt][blk][lane] x 16 B; fp32 [mt][in-tile][lane] x 16 B.
 // INIT: how the accumulators start.  INIT_ACC: the caller initialised them; INIT_ZERO: from zero (the asm stage

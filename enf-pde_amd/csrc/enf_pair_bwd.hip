@@ -63,6 +63,7 @@ struct PairBwdArgs {
   float inv_d;                          // 1 / (true num_hidden)
   const char* wzt; const float* wzb;    // ZF only: per (latent, head) [forward | backward] panels of W_zh, and c_zh
   float* dxq;                           // (B, N, dx) or nullptr: gradient w.r.t. the query coordinates, accumulated (atomics)
+  const unsigned* masks; int mask_B;    // STORE only: relu masks to linearise at (ENF_MASK_READ), or nullptr
   int B, N, Z, dx, inv, use_window, nsplit;
 };
 
@@ -429,11 +430,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     // ---------------- q-forward: logits -> attention probabilities
     float att[H], dlogit[H];
     Frags<BF16, KB> F;
+    unsigned maskq = 0u, maskv = 0u;     // STORE with A.masks: this tile's relu masks (query / value RFFNet layer)
     {
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acq, lane, quad, phq);
       make_frags<BF16, KB>(F, acc);
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pQ1, pV1, true, lane, c_bq1);
+      if constexpr (STORE) {
+        if (A.masks) {        // relu linearised at the masks' point: h1 = a1 where the bit is set (not max(a1, 0))
+          maskq = A.masks[relu_mask_index(b % A.mask_B, A.Z, bzc % A.Z, (A.N + 15) / 16, n0 / 16, 0, lane)];
+          maskv = A.masks[relu_mask_index(b % A.mask_B, A.Z, bzc % A.Z, (A.N + 15) / 16, n0 / 16, 1, lane)];
+          relu_apply_mask<NT>(acc, maskq);
+        }
+      }
+      const bool masked = STORE && A.masks != nullptr;
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float s = 0.f;
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int t = 0; t < NT; ++t) {
           const f32x4 u = rowvec(zv + h * D, t, quad);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s = fmaf(fmaxf(acc[t][i], 0.f), u[i], s);
+          for (int i = 0; i < 4; ++i) s = fmaf(masked ? acc[t][i] : fmaxf(acc[t][i], 0.f), u[i], s);
         }
         const float lg = xquad_sum(s) + cz[h] + win;
         att[h] = __expf(lg - A.lse[qrow * H + h]);
@@ -470,9 +480,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (acc[t][i] > 0.f) relu_mask |= 1u << (4 * t + i);
-          acc[t][i] = fmaxf(acc[t][i], 0.f);
+          if (STORE && A.masks) {
+            acc[t][i] = (maskv >> (4 * t + i)) & 1u ? acc[t][i] : 0.f;
+          } else {
+            if (acc[t][i] > 0.f) relu_mask |= 1u << (4 * t + i);
+            acc[t][i] = fmaxf(acc[t][i], 0.f);
+          }
         }
+      if (STORE && A.masks) relu_mask = maskv;
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
       if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, STAGE_RS2, true, lane, c_bf);
@@ -797,11 +812,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int i = 0; i < 4; ++i) dl[h][i] = __shfl(dlogit[h], (quad << 4) | (4 * quad + i), 64);
       const bool more = ti + 1 < my_tiles;
       float upart[H][NT];
+      // flipped tiles hold feature 16 mt + col of queries 4 quad + i: their mask bits sit in the words of lanes
+      // (col >> 2) * 16 + 4 quad + i, bit 4 mt + (col & 3)
+      unsigned mflip[4] = {0u, 0u, 0u, 0u};
+      const bool masked = STORE && A.masks != nullptr;
+      if (masked) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mflip[i] = (unsigned)__shfl((int)maskq, ((col >> 2) << 4) | (4 * quad + i), 64) >> (col & 3);
+      }
       panel_gemm_flip<KB, NT, BF16, ST_DD, NW, true, INIT_BIAS>(
           acc, F, P, ring, pQ1, gQ1, lane,
           [&](int mt) { const float bc = c_bq1[16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
           [&](int mt, const f32x4& af) {
-            const float r0 = relu_f(af[0]), r1 = relu_f(af[1]), r2 = relu_f(af[2]), r3 = relu_f(af[3]);
+            float r0, r1, r2, r3;
+            if (masked) {
+              r0 = (mflip[0] >> (4 * mt)) & 1u ? af[0] : 0.f; r1 = (mflip[1] >> (4 * mt)) & 1u ? af[1] : 0.f;
+              r2 = (mflip[2] >> (4 * mt)) & 1u ? af[2] : 0.f; r3 = (mflip[3] >> (4 * mt)) & 1u ? af[3] : 0.f;
+            } else { r0 = relu_f(af[0]); r1 = relu_f(af[1]); r2 = relu_f(af[2]); r3 = relu_f(af[3]); }
 #pragma unroll
             for (int h = 0; h < H; ++h) upart[h][mt] = dl[h][0] * r0 + dl[h][1] * r1 + dl[h][2] * r2 + dl[h][3] * r3;
           }, c_bq1);                                                                                             // a1
@@ -824,7 +851,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           for (int i = 0; i < 4; ++i) dh[i] = fmaf(dlogit[h], u[i], dh[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = acc[t][i] > 0.f ? dh[i] : 0.f;                                   // d a1
+        for (int i = 0; i < 4; ++i)
+          acc[t][i] = (masked ? ((maskq >> (4 * t + i)) & 1u) != 0u : acc[t][i] > 0.f) ? dh[i] : 0.f;             // d a1
       }
       Frags<BF16, KB> FA;
       make_frags<BF16, KB>(FA, acc);
@@ -922,11 +950,20 @@ static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
+// (process-wide, not thread_local: the framework's backward runs on its autograd thread)
+static const unsigned* g_bwd_masks = nullptr;
+static int g_bwd_mask_B = 1;
+extern "C" void enf_pair_bwd_set_masks(const unsigned* masks, int mask_B) {   // consumed by the next STORE launch
+  g_bwd_masks = masks; g_bwd_mask_B = mask_B > 0 ? mask_B : 1;
+}
+
 extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, const float* lse, const float* dybar, const float* delta, float* dlt,
                                    void* const* store, const char* wzt, const float* wzb, float* dxq, hipStream_t st) {
   PairBwdArgs A;
   A.dxq = dxq;
+  A.masks = store ? g_bwd_masks : nullptr; A.mask_B = g_bwd_mask_B;
+  if (store) g_bwd_masks = nullptr;
   const bool zf = !store && wzt && wzb && (size_t)m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
   A.wzt = wzt; A.wzb = wzb; A.inv_d = 1.0f / (float)m.Dt;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;

@@ -29,6 +29,7 @@ struct PairFwdArgs {
   const char* wz; const float* wzb; const char* wzu;   // z-fold only: per-latent mixer-input panels / biases (enf_wz.hip)
   float inv_d;                            // 1 / (true num_hidden)
   int xcd_remap;                          // z-fold: 1 when B % 8 == 0 (see the kernel)
+  unsigned* masks; int mask_mode, mask_B; // relu masks (ENF_MASK_*): buffer, 0 off / 1 write / 2 read, signals per mask set
   int B, N, Z, dx, inv, use_window, qg;   // qg: query groups per workgroup (1,2,4,8); ZS = 8/qg
 };
 
@@ -59,6 +60,9 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
       _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) ACC[t_] = rowvec(PTR, t_, quad); \
     }                                                                                  \
   } while (0)
+// relu-mask modes live in their own instantiation (MASKS): as wave-uniform runtime branches in the one kernel they cost
+// the default path 1.3 % (measured)
+#define K2_MASK_MODE (MASKS ? A.mask_mode : 0)
 #ifndef ENF_ZFOLD_WAVES
 #define ENF_ZFOLD_WAVES 8
 #endif
@@ -85,7 +89,7 @@ template <int D, int H, bool BF16, int NW> struct PairSmem {
 // ZFOLD: qg = 8 (every wave walks all latents, the 8 waves in step), and per head the gamma/beta GEMM, FiLM
 // and the mixer's first Dense are ONE D x D GEMM with the per-latent matrix W_zh of enf_wz.hip:
 //   a5_h = W_zh^T n + c_zh      (5 D x D GEMMs per pair instead of 9 D x D equivalents)
-template <int D, int H, bool BF16, bool ZFOLD>
+template <int D, int H, bool BF16, bool ZFOLD, bool MASKS>
 __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_kernel(PairFwdArgs A) {
   using Cfg = PairCfg<D, BF16>;
   constexpr int NW = PairWaves<ZFOLD>::NW, NTH = 64 * NW;
@@ -184,12 +188,18 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       STAMP(1);
       panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pQ1, pV1, active, lane, c_bq1);
       STAMP(2);
+      const bool mread = K2_MASK_MODE == 2;                       // wave-uniform
+      if (K2_MASK_MODE) {
+        const size_t mrow = relu_mask_index(b % A.mask_B, A.Z, active ? z : A.Z - 1, (A.N + 15) / 16, n0 / 16, 0, lane);
+        if (K2_MASK_MODE == 1 && active && n0 < A.N) A.masks[mrow] = relu_mask_of<NT>(acc);
+        if (mread) relu_apply_mask<NT>(acc, n0 < A.N ? A.masks[mrow] : 0u);
+      }
       if constexpr (ZFOLD && BF16) {
         // logits on the matrix pipe: rows 0..H-1 of the A operand are u_zh (bf16, packed by enf_wz_kernel),
         // B = relu(a1) fragments; lane (col, quad 0) register h then holds h1 . u_h of query `col`
         static_assert(H <= 4, "logit rows live in one quad");
         make_frags<BF16, KB>(F, acc);
-        relu_frags<BF16, KB>(F);
+        if (!mread) relu_frags<BF16, KB>(F);
         f32x4 lg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int blk = 0; blk < KB; ++blk) {
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
         for (int t = 0; t < NT; ++t) {
           const f32x4 u = rowvec(zv + h * D, t, quad);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s = fmaf(relu_f(acc[t][i]), u[i], s);
+          for (int i = 0; i < 4; ++i) s = fmaf(mread ? acc[t][i] : relu_f(acc[t][i]), u[i], s);
         }
         logit[h] = xquad_sum(s) + ltrow[enf_lt_off_c(H, D) + h] + win;
       }
@@ -221,8 +231,14 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       STAMP(4);
       panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pV1, pF, active, lane, c_bv1);
       STAMP(5);
+      const bool mread = K2_MASK_MODE == 2;
+      if (K2_MASK_MODE) {
+        const size_t mrow = relu_mask_index(b % A.mask_B, A.Z, active ? z : A.Z - 1, (A.N + 15) / 16, n0 / 16, 1, lane);
+        if (K2_MASK_MODE == 1 && active && n0 < A.N) A.masks[mrow] = relu_mask_of<NT>(acc);
+        if (mread) relu_apply_mask<NT>(acc, n0 < A.N ? A.masks[mrow] : 0u);
+      }
       make_frags<BF16, KB>(F, acc);
-      relu_frags<BF16, KB>(F);
+      if (!mread) relu_frags<BF16, KB>(F);
       K2_BIAS(acc, c_bf);
       STAMP(6);
       if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(z * H * PANEL_DD), active, lane, c_bf);
@@ -361,11 +377,14 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   }
 }
 
-template <int D, int H, bool BF16, bool ZFOLD>
+template <int D, int H, bool BF16, bool ZFOLD, bool MASKS = false>
 static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
+  if constexpr (!MASKS) {
+    if (A.mask_mode) return launch_pair_fwd<D, H, BF16, ZFOLD, true>(A, st);
+  }
   constexpr int NW = PairWaves<ZFOLD>::NW;
   using SM = PairSmem<D, H, BF16, NW>;
-  auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD>;
+  auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD, MASKS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL) != hipSuccess)
@@ -380,12 +399,21 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
 extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
 
 // wz / wzb: scratch for the z-fold variant (enf_workspace: W.wz, W.wzb), or NULL for the latent-split variant
+// (process-wide, not thread_local: the framework's backward runs on its autograd thread)
+static unsigned* g_fwd_masks = nullptr;
+static int g_fwd_mask_mode = 0, g_fwd_mask_B = 1;
+extern "C" void enf_pair_fwd_set_masks(unsigned* masks, int mode, int mask_B) {   // consumed by the next pair launch
+  g_fwd_masks = masks; g_fwd_mask_mode = masks ? mode : 0; g_fwd_mask_B = mask_B > 0 ? mask_B : 1;
+}
+
 extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, float* ybar, float* lse, char* wz, float* wzb, char* wzu,
                                    int run_fold, int run_pair, hipStream_t st) {
   PairFwdArgs A;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu; A.inv_d = 1.0f / (float)m.Dt;
   A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
+  A.masks = g_fwd_masks; A.mask_mode = run_pair ? g_fwd_mask_mode : 0; A.mask_B = g_fwd_mask_B;
+  if (run_pair) { g_fwd_masks = nullptr; g_fwd_mask_mode = 0; }
   // as many latent splits as there are latents to split (up to 8); the rest of the 8 waves take more queries
   int zs = 1;
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;

@@ -367,6 +367,28 @@ class EquivariantCrossAttentionNeF:
 
     __call__ = apply
 
+    # ------------------------------------------------------------------ relu masks (second-order terms by differences)
+    def relu_mask_buffer(self, B, N, Z, device):
+        """Device buffer for the relu masks of a (B, N, Z) problem (enf_relu_mask_bytes)."""
+        desc = self._desc(B, N, Z)
+        return torch.empty(int(_lib.load().enf_relu_mask_bytes(ctypes.byref(desc))) // 4, device=device, dtype=torch.int32)
+
+    def relu_masks(self, buf, mode, signals):
+        """Context manager: the next pair-kernel forward (any path) WRITES ("write") the relu masks of its pre-activations
+        into ``buf``, or the next forward and the next weight-gradient backward READ ("read") them -- relu linearised at the
+        point the masks were taken, for signals b, b + signals, ... alike (include/enf_hip.h: enf_set_relu_masks)."""
+        import contextlib
+        lib = _lib.load()
+
+        @contextlib.contextmanager
+        def cm():
+            _lib.check(lib.enf_set_relu_masks(_ptr(buf), {"write": 1, "read": 2}[mode], int(signals)))
+            try:
+                yield buf
+            finally:
+                lib.enf_set_relu_masks(None, 0, 1)
+        return cm()
+
     @torch.no_grad()
     def mse_value_and_latent_grads(self, params, x, p, a, gaussian_window_size, target, grad_scale=1.0):
         """loss = mean((nef.apply(params, x, p, a, window) - target)^2) and grad_scale * d loss / d(p, a, window) in one

@@ -22,16 +22,18 @@ half entering the loss negated, so that the pass returns the difference of the t
 perturbation); ``second_order="none"`` drops them (first-order MAML).
 
 Accuracy against exact double-backward of the oracle (scripts/meta_grad_err.py, tests/test_gpu_trainer.py; f32
-mode): first-order MAML is off by 7-50 % per tensor on the test problems -- the second-order terms matter; the
-finite-difference form brings 42 of the 46 weight tensors, the latent features and the inner learning rates to
-~1e-3..1e-2.  The four tensors feeding a relu (layers_0 kernel/bias of the two RFFNets) and the position
-initialisation stay at 2-20 %; their error is U-shaped in the step (95 % at 1e-3, 32 % at 5e-3, 22 % at 2e-2, 10 % at
-1e-1, 13 % at 3e-1 on the first test problem; the other tensors are best at 2e-2 and reach 2 % at 1e-1): noise of the
-first-order gradients on one side, truncation on the other, with a floor near 10 %.  Relu masks
-flipping under the finite perturbation were the suspected cause and are NOT it: an experiment that recorded the masks at
-phi_s in K2 and replayed them in both perturbed passes (relu linearised at phi_s, forward and K3) left these errors
-unchanged (0.22 -> 0.22, 0.093 -> 0.093; the other tensors moved from 7.7e-3 to 6.2e-3) and was removed again.  An exact
-a.e. second-order term needs tangent-mode (JVP) pair kernels -- not built.
+mode): first-order MAML is off by 7-50 % per tensor on the test problems -- the second-order terms matter.  Plain
+finite differences of the gradients brought 42 of the 46 weight tensors to ~1e-3..1e-2 but left the four tensors feeding
+a relu (layers_0 kernel / bias of the two RFFNets) and the position initialisation at 10-30 % FOR EVERY STEP SIZE: a
+difference of first-order gradients converges to the DISTRIBUTIONAL second derivative, in which every relu unit whose
+sign changes between phi_s - eps w and phi_s + eps w contributes a finite amount (their number scales with eps, each
+one's weight with 1/eps), while automatic differentiation -- the reference's jax.grad, the oracle -- has relu'' = 0.
+(scripts/meta_grad_fd_oracle.py reproduces this with the CPU oracle in fp64: same 22 % with free masks, 1e-3 -> 1e-8
+as the step shrinks with frozen masks.)  So the two perturbed passes run with the relu masks FROZEN at phi_s
+(``freeze_relu``; include/enf_hip.h: enf_set_relu_masks -- one extra pair-kernel forward per inner step records them,
+the forward and the weight-gradient backward of the perturbed pass replay them): every tensor, the latent initialisation
+and the inner learning rates then agree with exact second-order autograd to 1e-3 at fd_step 2e-2, 1e-4 at 5e-3 (the
+default) and 3-7e-5 at 1e-3.
 """
 import math
 from dataclasses import dataclass, field
@@ -98,7 +100,7 @@ def _full_grads(nef, weights, coords, img, masks, s, lat, keys):
     return loss.detach(), gw, gl
 
 
-def _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys):
+def _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys, relu_buf=None):
     """grads(plus) - grads(minus) of the step-s loss, w.r.t. the weights and the latents, in ONE training-path pass: the two
     latent sets run as one batch of 2B signals whose second half enters the loss with a minus sign (the outer step is
     launch-bound, so one pass of twice the batch costs about half of two passes)."""
@@ -108,21 +110,24 @@ def _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys):
     n_ori = nef.cross_attn_invariant.num_z_ori_dims
     xs = coords[masks[:, s]][None].expand(2 * B, -1, -1)
     ys = img[:, masks[:, s]]
-    out = nef.apply(_tree_from_tensors(w), xs, _pose(leaves, n_ori), leaves["a"], leaves.get("gaussian_window"))
-    loss = ((out[:B] - ys) ** 2).mean() - ((out[B:] - ys) ** 2).mean()
-    g = torch.autograd.grad(loss, w + [leaves[k] for k in keys], allow_unused=True)
+    import contextlib
+    with (nef.relu_masks(relu_buf, "read", B) if relu_buf is not None else contextlib.nullcontext()):
+        out = nef.apply(_tree_from_tensors(w), xs, _pose(leaves, n_ori), leaves["a"], leaves.get("gaussian_window"))
+        loss = ((out[:B] - ys) ** 2).mean() - ((out[B:] - ys) ** 2).mean()
+        g = torch.autograd.grad(loss, w + [leaves[k] for k in keys], allow_unused=True)
     gw = [torch.zeros_like(t) if gi is None else gi for t, gi in zip(w, g[:len(w)])]
     gl = {k: (torch.zeros_like(plus[k]) if gi is None else gi[:B] + gi[B:]) for k, gi in zip(keys, g[len(w):])}
     return gw, gl
 
 
 def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaussian_window=False,
-                   second_order="fd", fd_step=2e-2, noise_pos=0.0, generator=None, terminal=None):
+                   second_order="fd", fd_step=5e-3, noise_pos=0.0, generator=None, terminal=None, freeze_relu=True):
     """Value and gradient of the last-inner-step loss w.r.t. (nef weights, meta-init latents, inner lrs).
 
     Returns (loss, grads) with grads = {'nef': [46 tensors in ENF_W_* order], 'autodecoder': {key: (1,Z,.)},
     'meta_sgd_lrs': {key: like lrs[key]}}.
 
+    ``freeze_relu``: take the finite differences with the relu masks frozen at the unperturbed latents (module docstring).
     ``terminal(weights, lat, keys) -> (loss, d loss/d weights, {key: d loss/d lat[key]})`` replaces the objective on
     the fitted latents (default: the reconstruction loss on the last mask); dual_train_step passes the roll-out loss.
     """
@@ -170,7 +175,15 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
         eps = fd_step / wmax
         plus = {k: phis[s][k] + eps * w[k] for k in lam}
         minus = {k: phis[s][k] - eps * w[k] for k in lam}
-        gw_d, gl_d = _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys)
+        relu_buf = None
+        if freeze_relu and hasattr(nef, "relu_masks"):
+            # the relu masks AT phi_s: both perturbed passes then differentiate the same piecewise-linear branch, so their
+            # difference is the almost-everywhere second derivative (what jax.grad of the inner steps computes) instead of
+            # also counting the units that flip between phi_s - eps w and phi_s + eps w
+            relu_buf = nef.relu_mask_buffer(B, masks.shape[0], phis[s]["a"].shape[1], coords.device)
+            with torch.no_grad(), nef.relu_masks(relu_buf, "write", B):
+                _loss(nef, frozen, coords, img, masks, s, phis[s])
+        gw_d, gl_d = _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys, relu_buf)
         c = B / (2.0 * eps)
         g_theta = list(torch._foreach_add(g_theta, gw_d, alpha=-c))
         lam = {k: lam[k] - c * gl_d[k] if k in gl_d else lam[k] for k in lam}
@@ -198,7 +211,7 @@ class MetaSGDPDETrainer:
     also optimizer.learning_rate_ode, node.dt, node.method, dataset.traj_len_train, dataset.traj_len_out_horizon.
     """
 
-    def __init__(self, config, nef, outer_autodecoder, coords, seed=0, second_order="fd", fd_step=2e-2, ode_model=None):
+    def __init__(self, config, nef, outer_autodecoder, coords, seed=0, second_order="fd", fd_step=5e-3, ode_model=None):
         self.config, self.nef, self.outer_autodecoder, self.coords, self.seed = config, nef, outer_autodecoder, coords, seed
         self.second_order, self.fd_step = second_order, fd_step
         self.ode_model = ode_model

@@ -199,6 +199,21 @@ int enf_pair_backward_ex(const EnfDesc* d, const float* x, int64_t x_bstride, co
                          const float* lse, const float* dybar, const float* delta, float* dlt, void* const* store,
                          float* dx, void* stream);
 
+/* Relu masks.  Second-order terms taken as finite differences of FIRST-order gradients (the outer MAML step,
+ * pde_trainer.py:255) converge to the DISTRIBUTIONAL second derivative: relu units whose sign changes between the two
+ * perturbed points add a finite amount that automatic differentiation (relu'' = 0) never includes (20 % on the RFFNet
+ * layer-0 weights in the tests).  With ENF_MASK_WRITE the next pair-kernel forward records, per pair and relu layer (the
+ * two RFFNet layers), which pre-activations are positive; with ENF_MASK_READ the next pair-kernel forward and the next
+ * enf_pair_backward[_ex] WITH an activation store use the relu LINEARISED at those masks (h = a where the bit is set)
+ * instead of max(a, 0), for signals b, b + mask_signals, ... alike.  One 32-bit word per lane, 16-query tile, latent and
+ * layer: enf_relu_mask_bytes(d) for the shape that WRITES them (same N, Z; B = mask_signals).  The setting is consumed
+ * by those launches (one forward, one backward) and then reverts to ENF_MASK_OFF.  Process-wide state: one trainer. */
+#define ENF_MASK_OFF 0
+#define ENF_MASK_WRITE 1
+#define ENF_MASK_READ 2
+size_t enf_relu_mask_bytes(const EnfDesc* d);
+int enf_set_relu_masks(void* masks, int mode, int mask_signals);
+
 /* Reconstruction loss of the inner loop and its gradient in one pass (pde_trainer.py:185):
  *   *loss += mean((out - target)^2)   (the caller zeroes *loss),   dout = 2 (out - target) / n * grad_scale  (dout may be NULL) */
 int enf_mse_value_grad(const float* out, const float* target, size_t n, float grad_scale, float* dout, float* loss,

@@ -13,10 +13,11 @@ for kw in (dict(), dict(B=8, Ns=64, side=8, Z=16)):
     nef = build_nef(cfg, "f32"); params = nef.load_params(prm, device=cuda)
     t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
     res = {}
-    for mode, step in (("none", 0), ("fd", 2e-2), ("fd", 5e-2), ("fd", 1e-1), ("fd", 3e-1)):
+    # columns: first-order | fd, masks free, step 2e-2 | fd, relu masks frozen at phi_s, steps 2e-2, 5e-3, 1e-3
+    for mode, step, frz in (("none", 0, False), ("fd", 2e-2, False), ("fd", 2e-2, True), ("fd", 5e-3, True), ("fd", 1e-3, True)):
         _, g = meta_gradients(nef, params, {k: t(v) for k, v in lat0.items()}, {k: t(v) for k, v in lrs.items()}, t(coords), t(img),
-                              torch.tensor(masks, device=cuda), second_order=mode, fd_step=step or 5e-3)
-        res[(mode, step)] = g
+                              torch.tensor(masks, device=cuda), second_order=mode, fd_step=step or 5e-3, freeze_relu=frz)
+        res[(mode, step, frz)] = g
     print("problem", kw)
     for i, path in enumerate(TENSOR_PATHS):
         nb = np.linalg.norm(gw_r[i])

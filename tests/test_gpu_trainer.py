@@ -67,17 +67,21 @@ def test_meta_gradient_fd_matches_exact_second_order(cuda):
     for path, a, b in zip(TENSOR_PATHS, g["nef"], gw_r):
         nb = np.linalg.norm(b)
         e = np.linalg.norm(a.cpu().numpy() - b) / (nb if nb > 1e-3 * gmax else gmax)
-        # the four relu-adjacent tensors are the ill-conditioned ones of the finite-difference form (pde_trainer.py docstring)
-        tol = 0.3 if path[-3:-1] == ("layers_0", "linear") else 2e-2
+        tol = 2e-3          # relu masks frozen at the unperturbed latents (pde_trainer.py docstring); 0.1-0.3 without
         if not e < tol:
             bad.append(("/".join(path[-3:]), e))
     assert not bad, bad
-    for k, tol in (("a", 3e-2), ("p_pos", 0.3)):
+    for k, tol in (("a", 2e-3), ("p_pos", 5e-3)):
         e = np.linalg.norm(g["autodecoder"][k].cpu().numpy() - gl_r[k]) / max(np.linalg.norm(gl_r[k]), 1e-12)
         assert e < tol, (k, e)
     for k in ("p_pos", "a"):
         e = np.linalg.norm(g["meta_sgd_lrs"][k].cpu().numpy() - gr_r[k]) / max(np.linalg.norm(gr_r[k]), 1e-12)
-        assert e < 3e-2, (k, e)
+        assert e < 2e-3, (k, e)
+    # without the frozen masks the relu-adjacent tensors are off by 10-30 % whatever the step
+    _, gf = meta_gradients(nef, params, {k: t(v) for k, v in lat0.items()}, {k: t(v) for k, v in lrs.items()}, t(coords),
+                           t(img), torch.tensor(masks, device=cuda), second_order="fd", freeze_relu=False)
+    i0 = [p[-3:] for p in TENSOR_PATHS].index(("layers_0", "linear", "kernel"))
+    assert np.linalg.norm(gf["nef"][i0].cpu().numpy() - gw_r[i0]) / np.linalg.norm(gw_r[i0]) > 2e-2
     # and the second-order terms matter: first-order MAML is measurably different on this problem
     _, g1 = meta_gradients(nef, params, {k: t(v) for k, v in lat0.items()}, {k: t(v) for k, v in lrs.items()}, t(coords),
                            t(img), torch.tensor(masks, device=cuda), second_order="none")

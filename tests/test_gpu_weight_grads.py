@@ -119,3 +119,39 @@ def test_training_path_matches_inference_path(cuda):
         res.append((out.detach(), tp.grad, ta.grad, ts.grad))
     for u, v in zip(*res):
         assert torch.allclose(u, v, rtol=2e-3, atol=2e-4 * float(v.abs().max()))
+
+
+def test_relu_masks_replay(cuda):
+    """enf_set_relu_masks: masks written at a point and replayed AT THE SAME POINT change nothing (the linearised relu
+    equals the relu there), forward and every gradient; replayed at a perturbed point they differ from the free relu."""
+    cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=8, O=1, freq=(0.5, 1.0))
+    prm = R.init_params(5, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 2, 40, 9, 6)
+    nef = build_nef(cfg, "f32")
+    P = nef.load_params(prm, device=cuda)
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    w = t(np.random.default_rng(7).standard_normal((2, 40, 1)))
+
+    def run(pp, masks=None):
+        ws = [v.detach().clone().requires_grad_(True) for v in nef.param_tensors(P)]
+        from enf_pde_amd.fitting.trainers.pde_trainer import _tree_from_tensors
+        import contextlib
+        pa, aa = t(pp, True), t(a, True)
+        with (nef.relu_masks(masks, "read", 2) if masks is not None else contextlib.nullcontext()):
+            out = nef.apply(_tree_from_tensors(ws), t(x), pa, aa, t(s))
+            g = torch.autograd.grad((out * w).sum(), ws + [pa, aa], allow_unused=True)
+        return out.detach(), [gi for gi in g if gi is not None]
+    buf = nef.relu_mask_buffer(2, 40, 9, cuda)
+    buf.zero_()
+    with torch.no_grad(), nef.relu_masks(buf, "write", 2):
+        nef.apply(P, t(x), t(p), t(a), t(s))
+    assert int((buf != 0).sum()) > 0
+    o0, g0 = run(p)
+    o1, g1 = run(p, buf)
+    assert torch.equal(o0, o1) and all(torch.equal(u, v) for u, v in zip(g0, g1))
+    p2 = p + 0.05
+    o2, g2 = run(p2)
+    o3, g3 = run(p2, buf)                       # relu linearised at p, evaluated at p2
+    assert not torch.equal(o2, o3)
+    o4, _ = run(p)                              # the setting is consumed: the next pass is a plain one again
+    assert torch.equal(o4, o0)
