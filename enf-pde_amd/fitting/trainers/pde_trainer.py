@@ -33,7 +33,8 @@ as the step shrinks with frozen masks.)  So the two perturbed passes run with th
 (``freeze_relu``; include/enf_hip.h: enf_set_relu_masks -- one extra pair-kernel forward per inner step records them,
 the forward and the weight-gradient backward of the perturbed pass replay them): every tensor, the latent initialisation
 and the inner learning rates then agree with exact second-order autograd to 1e-3 at fd_step 2e-2, 1e-4 at 5e-3 (the
-default) and 3-7e-5 at 1e-3.
+f32 default) and 3-7e-5 at 1e-3.  bf16 kernels (scripts/meta_grad_err_bf16.py): best at 2e-2 (their default): median 7e-3
+per tensor, 4-8 % on the worst (the bf16 noise floor of the first-order weight gradients themselves).
 """
 import math
 from dataclasses import dataclass, field
@@ -121,7 +122,7 @@ def _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys, relu_buf
 
 
 def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaussian_window=False,
-                   second_order="fd", fd_step=5e-3, noise_pos=0.0, generator=None, terminal=None, freeze_relu=True):
+                   second_order="fd", fd_step=None, noise_pos=0.0, generator=None, terminal=None, freeze_relu=True):
     """Value and gradient of the last-inner-step loss w.r.t. (nef weights, meta-init latents, inner lrs).
 
     Returns (loss, grads) with grads = {'nef': [46 tensors in ENF_W_* order], 'autodecoder': {key: (1,Z,.)},
@@ -133,6 +134,8 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
     """
     if second_order not in ("fd", "none"):
         raise ValueError("second_order must be 'fd' or 'none'")
+    if fd_step is None:      # truncation (~step^2) against the rounding of the first-order gradients (~1 / step): bf16 kernels
+        fd_step = 2e-2 if getattr(nef, "precision", "f32") in ("bf16", "bfloat16") else 5e-3      # are 100x noisier
     B = img.shape[0]
     S = masks.shape[1] - 1
     weights = nef.param_tensors(nef_params)
@@ -211,7 +214,7 @@ class MetaSGDPDETrainer:
     also optimizer.learning_rate_ode, node.dt, node.method, dataset.traj_len_train, dataset.traj_len_out_horizon.
     """
 
-    def __init__(self, config, nef, outer_autodecoder, coords, seed=0, second_order="fd", fd_step=5e-3, ode_model=None):
+    def __init__(self, config, nef, outer_autodecoder, coords, seed=0, second_order="fd", fd_step=None, ode_model=None):
         self.config, self.nef, self.outer_autodecoder, self.coords, self.seed = config, nef, outer_autodecoder, coords, seed
         self.second_order, self.fd_step = second_order, fd_step
         self.ode_model = ode_model
