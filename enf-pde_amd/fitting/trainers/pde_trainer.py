@@ -30,8 +30,8 @@ sign changes between phi_s - eps w and phi_s + eps w contributes a finite amount
 one's weight with 1/eps), while automatic differentiation -- the reference's jax.grad, the oracle -- has relu'' = 0.
 (scripts/meta_grad_fd_oracle.py reproduces this with the CPU oracle in fp64: same 22 % with free masks, 1e-3 -> 1e-8
 as the step shrinks with frozen masks.)  So the two perturbed passes run with the relu masks FROZEN at phi_s
-(``freeze_relu``; include/enf_hip.h: enf_set_relu_masks -- one extra pair-kernel forward per inner step records them,
-the forward and the weight-gradient backward of the perturbed pass replay them): every tensor, the latent initialisation
+(``freeze_relu``; include/enf_hip.h: enf_set_relu_masks -- the forward sweep's own pair-kernel forward at phi_s records
+them, the forward and the weight-gradient backward of the perturbed pass replay them): every tensor, the latent initialisation
 and the inner learning rates then agree with exact second-order autograd to 1e-3 at fd_step 2e-2, 1e-4 at 5e-3 (the
 f32 default) and 3-7e-5 at 1e-3.  bf16 kernels (scripts/meta_grad_err_bf16.py): best at 2e-2 (their default): median 7e-3
 per tensor, 4-8 % on the worst (the bf16 noise floor of the first-order weight gradients themselves).
@@ -149,9 +149,14 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
         return k == "gaussian_window" and not optimize_gaussian_window
 
     # ---- forward sweep, keeping every phi_s and g_s
-    phis, gs = [], []
+    phis, gs, relu_bufs = [], [], []
+    freeze = second_order == "fd" and freeze_relu and hasattr(nef, "relu_masks")
+    import contextlib
     for s in range(S):
-        g = _latent_grads(nef, frozen, coords, img, masks, s, lat, keys)
+        # (the forward of this pass also records the relu masks at phi_s for the adjoint sweep's frozen-mask differences)
+        relu_bufs.append(nef.relu_mask_buffer(B, masks.shape[0], lat["a"].shape[1], coords.device) if freeze else None)
+        with (nef.relu_masks(relu_bufs[s], "write", B) if freeze else contextlib.nullcontext()):
+            g = _latent_grads(nef, frozen, coords, img, masks, s, lat, keys)
         g = {k: (torch.zeros_like(lat[k]) if (k not in g or masked(k)) else g[k] * B) for k in lat}    # pde_trainer.py:207
         phis.append(lat)
         gs.append(g)
@@ -178,15 +183,10 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
         eps = fd_step / wmax
         plus = {k: phis[s][k] + eps * w[k] for k in lam}
         minus = {k: phis[s][k] - eps * w[k] for k in lam}
-        relu_buf = None
-        if freeze_relu and hasattr(nef, "relu_masks"):
-            # the relu masks AT phi_s: both perturbed passes then differentiate the same piecewise-linear branch, so their
-            # difference is the almost-everywhere second derivative (what jax.grad of the inner steps computes) instead of
-            # also counting the units that flip between phi_s - eps w and phi_s + eps w
-            relu_buf = nef.relu_mask_buffer(B, masks.shape[0], phis[s]["a"].shape[1], coords.device)
-            with torch.no_grad(), nef.relu_masks(relu_buf, "write", B):
-                _loss(nef, frozen, coords, img, masks, s, phis[s])
-        gw_d, gl_d = _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys, relu_buf)
+        # with the relu masks AT phi_s both perturbed passes differentiate the same piecewise-linear branch, so their
+        # difference is the almost-everywhere second derivative (what jax.grad of the inner steps computes) instead of
+        # also counting the units that flip between phi_s - eps w and phi_s + eps w
+        gw_d, gl_d = _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys, relu_bufs[s])
         c = B / (2.0 * eps)
         g_theta = list(torch._foreach_add(g_theta, gw_d, alpha=-c))
         lam = {k: lam[k] - c * gl_d[k] if k in gl_d else lam[k] for k in lam}
