@@ -183,3 +183,86 @@ extern "C" int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const flo
 #undef ODE_DKB
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Polynomial features of the pair invariants (PolynomialFeatures, ponita_ode_g.py:15-26): the Kronecker powers
+// [x, x(x)x, (x(x)x)(x)x, ...] of an I-vector, degree + 1 blocks, F = I + I^2 + ... values per pair.  Feature k of block
+// d (0-based) is the product of d + 1 components whose indices are the base-I digits of its offset in the block, most
+// significant first (the reference's einsum('...i,...j->...ij', prev, x) appends the new factor as the LAST index).
+// Forward: one thread per (pair, feature), writes coalesced along the feature axis.  Backward: one 64-lane wave per pair:
+// lanes stride over the features, d x_i accumulates  dF_k * prod_{other factors}  for every position holding index i,
+// then a wave reduction.  The reference materialises every intermediate power (and autograd their gradients).
+struct OdePolyArgs { const float* x; const float* dF; float* out; long P; int I, degree, F; };
+
+__device__ __forceinline__ void ode_poly_decode(int k, int I, int& d, int& off) {
+  d = 0;
+  int blk = I;
+  off = k;
+  while (off >= blk) { off -= blk; blk *= I; ++d; }
+}
+
+__global__ __launch_bounds__(256) void enf_ode_poly_fwd_kernel(OdePolyArgs A) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= A.P * A.F) return;
+  const long p = idx / A.F;
+  const int k = (int)(idx - p * A.F);
+  int d, off;
+  ode_poly_decode(k, A.I, d, off);
+  const float* x = A.x + p * A.I;
+  float v = 1.f;
+  for (int j = 0; j <= d; ++j) { v *= x[off % A.I]; off /= A.I; }     // (order of the factors is irrelevant to the product)
+  A.out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void enf_ode_poly_bwd_kernel(OdePolyArgs A) {
+  const int lane = threadIdx.x & 63;
+  const long p = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= A.P) return;                                              // wave-uniform
+  float xi[8], g[8];
+  for (int i = 0; i < 8; ++i) { xi[i] = i < A.I ? A.x[p * A.I + i] : 0.f; g[i] = 0.f; }
+  const float* dF = A.dF + p * A.F;
+  for (int k = lane; k < A.F; k += 64) {
+    int d, off;
+    ode_poly_decode(k, A.I, d, off);
+    int dig[8];
+    for (int j = 0; j <= d; ++j) { dig[j] = off % A.I; off /= A.I; }
+    const float gk = dF[k];
+    for (int j = 0; j <= d; ++j) {                                   // derivative w.r.t. the factor at position j
+      float v = gk;
+      for (int m = 0; m <= d; ++m)
+        if (m != j) v *= xi[dig[m]];
+      g[dig[j]] += v;
+    }
+  }
+  for (int i = 0; i < A.I; ++i) {
+    float v = g[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) A.out[p * A.I + i] = v;
+  }
+}
+
+extern "C" int enf_ode_poly_num_features(int I, int degree) {
+  if (I < 1 || I > 8 || degree < 0 || degree > 7) return ENF_EUNSUPPORTED;
+  long f = 0, b = 1;
+  for (int d = 0; d <= degree; ++d) { b *= I; f += b; if (f > (1 << 20)) return ENF_EUNSUPPORTED; }
+  return (int)f;
+}
+
+extern "C" int enf_ode_poly_forward(int64_t P, int I, int degree, const float* x, float* feat, void* stream) {
+  const int F = enf_ode_poly_num_features(I, degree);
+  if (F < 0) return F;
+  if (P <= 0 || !x || !feat) return ENF_EINVAL;
+  OdePolyArgs A{x, nullptr, feat, (long)P, I, degree, F};
+  const long n = (long)P * F;
+  hipLaunchKernelGGL(enf_ode_poly_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+}
+
+extern "C" int enf_ode_poly_backward(int64_t P, int I, int degree, const float* x, const float* dfeat, float* dx, void* stream) {
+  const int F = enf_ode_poly_num_features(I, degree);
+  if (F < 0) return F;
+  if (P <= 0 || !x || !dfeat || !dx) return ENF_EINVAL;
+  OdePolyArgs A{x, dfeat, dx, (long)P, I, degree, F};
+  hipLaunchKernelGGL(enf_ode_poly_bwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A);
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+}

@@ -109,13 +109,43 @@ def sep_gconv(a, kb, W, bias=None):
     return _SepGconv.apply(a, kb, W, bias)
 
 
+class _PolyFeatures(torch.autograd.Function):
+    """Kronecker powers of the pair invariants in one HIP launch each way (csrc/enf_ode.hip: enf_ode_poly_*)."""
+
+    @staticmethod
+    def forward(ctx, x, degree):
+        lib = _lib.load()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        P, I = x2.shape
+        F = lib.enf_ode_poly_num_features(I, degree)
+        _lib.check(F if F < 0 else 0)
+        out = torch.empty((P, F), device=x.device, dtype=torch.float32)
+        _lib.check(lib.enf_ode_poly_forward(P, I, degree, _ptr(x2), _ptr(out), _stream(x.device)))
+        ctx.save_for_backward(x2)
+        ctx.degree, ctx.shape = degree, x.shape
+        return out.view(*x.shape[:-1], F)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x2,) = ctx.saved_tensors
+        P, I = x2.shape
+        g2 = g.reshape(P, -1).contiguous()
+        dx = torch.empty_like(x2)
+        _lib.check(lib.enf_ode_poly_backward(P, I, ctx.degree, _ptr(x2), _ptr(g2), _ptr(dx), _stream(x2.device)))
+        return dx.view(ctx.shape), None
+
+
 class PolynomialFeatures:
-    """[x, x(x)x, ...]: degree + 1 Kronecker powers, flattened and concatenated (ponita_ode_g.py:15-26)."""
+    """[x, x(x)x, ...]: degree + 1 Kronecker powers, flattened and concatenated (ponita_ode_g.py:15-26).  Device fp32
+    tensors go through the fused HIP kernels; host tensors (tests of the host logic) through the definition below."""
 
     def __init__(self, degree):
         self.degree = degree
 
     def __call__(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 8:
+            return _PolyFeatures.apply(x, self.degree)
         out = [x]
         for _ in range(self.degree):
             out.append((out[-1][..., :, None] * x[..., None, :]).flatten(-2))

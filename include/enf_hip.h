@@ -233,6 +233,13 @@ int enf_ode_conv_forward(int B, int Z, int J, int C, const float* a, const float
                          int64_t kb_stride_s, const float* W, const float* bias, float* out, void* stream);
 int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const float* a, const float* g, const float* W, float* dkb,
                                 void* stream);
+/* PolynomialFeatures (ponita_ode_g.py:15-26) of the P = B Z^2 pair invariants x (P, I): the Kronecker powers
+ * [x, x(x)x, ..., x^(x)(degree+1)] concatenated, F = I + I^2 + ... + I^(degree+1) values per pair (enf_ode_poly_num_features;
+ * 340 for I = 4, degree = 3), in the reference's order (each power appends its new factor as the last index).
+ * forward: feat (P, F);  backward: dx (P, I) = J^T dfeat.  I <= 8, degree <= 7.  No intermediate power is materialised. */
+int enf_ode_poly_num_features(int I, int degree);
+int enf_ode_poly_forward(int64_t P, int I, int degree, const float* x, float* feat, void* stream);
+int enf_ode_poly_backward(int64_t P, int I, int degree, const float* x, const float* dfeat, float* dx, void* stream);
 
 /* Forward pair-kernel variant: -1 = choose by problem size (default), 0 = latent-split, 1 = z-fold
  * (DESIGN.md 5).  Also settable with ENF_ZFOLD=0/1 in the environment.  Affects enf_workspace_bytes /

@@ -37,6 +37,24 @@ def test_sep_gconv_matches_einsum(cuda, B, Z, J, C, bias):
         assert rel(dev_in[i].grad.cpu().double().numpy(), ref_in[i].grad.numpy()) < 2e-5, name
 
 
+@pytest.mark.parametrize("I,degree", [(4, 3), (3, 3), (5, 3), (1, 3), (2, 2), (6, 1)])
+def test_poly_features_match_definition(cuda, I, degree):
+    """enf_ode_poly_forward / _backward against the reference's definition (einsum chain, ponita_ode_g.py:22-26) in fp64."""
+    from enf_pde_amd.fitting.ode_models import PolynomialFeatures
+    g = torch.Generator().manual_seed(I * 10 + degree)
+    x = torch.randn(3, 5, 7, I, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    ref = OT.poly_features(xr, degree)
+    w = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * w).sum().backward()
+    xd = x.to(cuda, torch.float32).requires_grad_(True)
+    out = PolynomialFeatures(degree)(xd)
+    assert out.shape == ref.shape == (3, 5, 7, O.num_poly_features(I, degree))
+    (out * w.to(cuda, torch.float32)).sum().backward()
+    assert rel(out.detach().cpu().double().numpy(), ref.detach().numpy()) < 1e-6
+    assert rel(xd.grad.cpu().double().numpy(), xr.grad.numpy()) < 1e-5
+
+
 def test_sep_gconv_rejects_unsupported(cuda):
     from enf_pde_amd.fitting.ode_models import sep_gconv
     z = lambda *s: torch.zeros(*s, device=cuda)
