@@ -25,8 +25,8 @@ def _get(tree, path):
     return tree
 
 
-def _problem(seed=0, D=64, H=2, C=8, Z=9, side=8, B=3, S=2, Ns=32):
-    cfg = make_cfg("rel_pos_periodic", D=D, H=H, C=C, O=1)
+def _problem(seed=0, D=64, H=2, C=8, Z=9, side=8, B=3, S=2, Ns=32, invariant="rel_pos_periodic"):
+    cfg = make_cfg(invariant, D=D, H=H, C=C, O=1)
     prm = R.init_params(seed, cfg, jitter=0.1)
     rng = np.random.default_rng(seed + 1)
     lin = np.linspace(-1, 1, side)
@@ -36,6 +36,11 @@ def _problem(seed=0, D=64, H=2, C=8, Z=9, side=8, B=3, S=2, Ns=32):
             "a": 1 + 0.1 * rng.standard_normal((1, Z, C)), "gaussian_window": np.full((1, Z, 1), 2.0 / 3)}
     lrs = {"p_pos": np.array([0.5]), "a": np.full((C,), 2.0) * (1 + 0.1 * rng.standard_normal(C)), "gaussian_window": np.array([0.0])}
     masks = np.stack([rng.permutation(side * side)[:Ns] for _ in range(S + 1)], 1)
+    if invariant == "ponita":                                     # poses carry an orientation with its own learning rate
+        lat0["p_ori"] = rng.uniform(-np.pi, np.pi, (1, Z, 1))
+        lrs["p_ori"] = np.array([0.3])
+        lat0 = {k: lat0[k] for k in ("p_pos", "p_ori", "a", "gaussian_window")}
+        lrs = {k: lrs[k] for k in ("p_pos", "p_ori", "a", "gaussian_window")}
     return cfg, prm, coords, img, lat0, lrs, masks
 
 
@@ -89,6 +94,25 @@ def test_meta_gradient_fd_matches_exact_second_order(cuda):
     d1 = np.linalg.norm(g1["nef"][i].cpu().numpy() - gw_r[i]) / np.linalg.norm(gw_r[i])
     d2 = np.linalg.norm(g["nef"][i].cpu().numpy() - gw_r[i]) / np.linalg.norm(gw_r[i])
     assert d1 > 5e-2 > d2, (d1, d2)
+
+
+def test_meta_gradient_with_orientations(cuda):
+    """The same for the ponita invariant: the pose splits into p_pos / p_ori (own inner learning rate, (cos, sin) embedding)."""
+    cfg, prm, coords, img, lat0, lrs, masks = _problem(seed=5, B=4, Ns=48, Z=9, invariant="ponita")
+    loss_r, gw_r, gl_r, gr_r = _oracle_meta_grads(cfg, prm, coords, img, lat0, lrs, masks)
+    nef = build_nef(cfg, "f32")
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    loss, g = meta_gradients(nef, params, {k: t(v) for k, v in lat0.items()}, {k: t(v) for k, v in lrs.items()}, t(coords),
+                             t(img), torch.tensor(masks, device=cuda), second_order="fd")
+    assert abs(float(loss) - loss_r) < 1e-5 * max(1.0, abs(loss_r))
+    gmax = max(np.linalg.norm(x) for x in gw_r)
+    for path, a, b in zip(TENSOR_PATHS, g["nef"], gw_r):
+        nb = np.linalg.norm(b)
+        assert np.linalg.norm(a.cpu().numpy() - b) / (nb if nb > 1e-3 * gmax else gmax) < 2e-3, path
+    for k in ("p_pos", "p_ori", "a"):
+        assert np.linalg.norm(g["autodecoder"][k].cpu().numpy() - gl_r[k]) / max(np.linalg.norm(gl_r[k]), 1e-12) < 5e-3, k
+        assert np.linalg.norm(g["meta_sgd_lrs"][k].cpu().numpy() - gr_r[k]) / max(np.linalg.norm(gr_r[k]), 1e-12) < 5e-3, k
 
 
 def test_nef_train_step_follows_optax_rules(cuda):
