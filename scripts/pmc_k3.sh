@@ -1,0 +1,33 @@
+#!/bin/bash
+# PMC passes over the forward pair kernel (scripts/prof_fwd.py bwd); summaries -> gpurun_out/pmc_<tag>/
+# usage: scripts/pmc_k3.sh TAG  (run on the GPU box through gpurun)
+TAG=${1:-k3}
+REPO=$PWD
+OUT=$REPO/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
+           "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $REPO/scripts/prof_fwd.py bwd > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+done
+python3 - <<PY
+import csv,glob,collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"].split("(")[0]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("$OUT/summary.txt","w") as o:
+    for k,d in acc.items():
+        if "pair_bwd" not in k and "pair_fwd" not in k and "wz" not in k and "tail" not in k: continue
+        o.write(k+"\n")
+        for c,v in sorted(d.items()):
+            o.write(f"  {c:32s} n={len(v):3d} mean={sum(v)/len(v):.4g}\n")
+print(open("$OUT/summary.txt").read())
+PY
