@@ -34,4 +34,4 @@ def solve_latent_ode(f, latents, t0, tf, h, method="rk4", stop_gradient=False):
             x = tuple(None if xi is None else xi.detach() for xi in x)
         traj.append(step(f, x, t, h))
         t += h
-    return tuple(torch.stack([s[i] for s in traj], 1) for i in range(3))
+    return tuple(None if traj[0][i] is None else torch.stack([s[i] for s in traj], 1) for i in range(3))

@@ -88,6 +88,9 @@ def step():
 
 
 ms_step = timed(step, max(3, iters // 4))
+if os.environ.get("ODE_PHASE") == "step":          # profiling aid: only the eager train step
+    print(json.dumps({"ms_ode_train_step": ms_step}))
+    sys.exit(0)
 with torch.no_grad():
     ms_val = timed(lambda: tr.val_step(state[0], traj), max(3, iters // 4))
 print(json.dumps({"workload": f"ponita ODE, B={B} Z={Z} C={C} hidden={H} basis={J} layers=3 degree=3 (340 features)",
