@@ -82,19 +82,18 @@ extern "C" int enf_debug_read_stamps_bwd(unsigned long long* dst) {
 #define BSTAMP(k) do {} while (0)
 #endif
 
-// one row of a materialised activation / delta = this lane's share of a fragment set
+// one row of a materialised activation / delta = this lane's share of a fragment set.
+// bf16: the 8 values of a fragment go out as ONE 16-byte store at columns 32 blk + 8 quad + j, i.e. the row is stored
+// with its columns PERMUTED inside every 32-block (true feature = 32 blk + 4 quad + j for j < 4, 32 blk + 16 + 4 quad +
+// j - 4 otherwise; ENF_S_* in include/enf_hip.h).  Every buffer uses the same permutation, the consumers are products
+// X^T delta over the pair axis, so the caller un-permutes the small D x D results instead.  Half the store instructions
+// and 64-byte instead of 32-byte row segments: the store is what bounds this instantiation.
 template <bool BF16, int KB>
 DEV void store_frags(void* base, size_t row, int D, const Frags<BF16, KB>& F, int quad) {
   if constexpr (BF16) {
     __bf16* p = reinterpret_cast<__bf16*>(base) + row * D;
 #pragma unroll
-    for (int blk = 0; blk < KB; ++blk) {
-      bf16x4 lo, hi;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { lo[i] = F.f[blk][i]; hi[i] = F.f[blk][4 + i]; }
-      *reinterpret_cast<bf16x4*>(p + 32 * blk + 4 * quad) = lo;
-      *reinterpret_cast<bf16x4*>(p + 32 * blk + 16 + 4 * quad) = hi;
-    }
+    for (int blk = 0; blk < KB; ++blk) *reinterpret_cast<bf16x8*>(p + 32 * blk + 8 * quad) = F.f[blk];
   } else {
     float* p = reinterpret_cast<float*>(base) + row * D;
 #pragma unroll

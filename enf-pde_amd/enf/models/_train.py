@@ -222,6 +222,19 @@ class _PairFunction(torch.autograd.Function):
                 gAGB[:, HD + h * D:HD + (h + 1) * D] += _xt_dot(sl[S.ENF_S_NH], DB)
                 gBGB[h * D:(h + 1) * D] += _col_sum(DG)
                 gBGB[HD + h * D:HD + (h + 1) * D] += _col_sum(DB)
+        if bf16:
+            # the bf16 store keeps the MFMA fragment order: columns permuted inside every 32-block (include/enf_hip.h,
+            # ENF_S_*); every buffer alike, so the products come out permuted in rows and columns: undo it here
+            c = torch.arange(D, device=dev)
+            j = c % 8
+            true = 32 * (c // 32) + torch.where(j < 4, 4 * ((c % 32) // 8) + j, 16 + 4 * ((c % 32) // 8) + j - 4)
+            inv = torch.empty_like(true)
+            inv[true] = c                                   # stored column of each true feature
+            inv2 = torch.cat([inv + k * D for k in range(2 * H)])
+            gAQ1, gAV1, gAF, gAM = (m[inv][:, inv] for m in (gAQ1, gAV1, gAF, gAM))
+            gAGB = gAGB[inv][:, inv2]
+            gBQ1, gBV1, gBF, gBM = (v[inv] for v in (gBQ1, gBV1, gBF, gBM))
+            gBGB = gBGB[inv2]
         assert dlt.shape[1] == stride
         # ENF_P_* order: AQ1,BQ1, AV1,BV1, AF,BF, AGB,BGB, AM,BM, COEFQ,COEFV (frozen: RFF:87-90)
         return (dx_out(), dlt, None, gAQ1, gBQ1, gAV1, gBV1, gAF, gBF, gAGB, gBGB, gAM, gBM, None, None)

@@ -172,6 +172,10 @@ enum {   /* effective per-pair parameters, plain fp32, kernels (in, out) */
  * GEMM dW = X^T delta over the pair axis:   AQ1: EQ^T DA1   AV1: EV^T DA2   AF: G1^T DA3
  *   AGB[:, gamma_h|beta_h]: NH^T DG_h | NH^T DB_h     AM: sum_h V_h^T DA5_h    biases: column sums of delta */
 enum { ENF_S_EQ = 0, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0 /* + 4h: V, DA5, DG, DB */ };
+/* Column order of the stored rows.  ENF_PREC_F32: natural.  ENF_PREC_BF16: permuted inside every block of 32 columns --
+ * stored column 32 b + 8 q + j (q < 4, j < 8) holds feature 32 b + 4 q + j for j < 4 and 32 b + 16 + 4 q + (j - 4)
+ * otherwise (the MFMA operand fragments go out as they sit in registers, one 16-byte store each).  All buffers share the
+ * permutation, so X^T delta comes out with rows and columns permuted alike: un-permute the D x D result. */
 #define ENF_NUM_STORE(H) (7 + 4 * (H))
 
 int enf_lt_layout(const EnfDesc* d, int* stride, int* off_u, int* off_v0, int* off_pose, int* off_wcoef, int* off_c);
