@@ -46,9 +46,13 @@ def check(cuda, cfg, B, N, Z, precision, seed=0, check_sigma=True):
     _, rp, ra, rs = ref_grads(prm, cfg, x, p, a, s, w)
     nef = build_nef(cfg, precision)
     _, gp, ga, gs = hip_grads(cuda, nef, prm, x, p, a, s, w)
-    errs = {"p": rel(gp, rp) if np.linalg.norm(rp) > 0 else np.abs(gp).max(), "a": rel(ga, ra)}
+    # a reference gradient that vanishes identically (one latent: the softmax no longer sees its logit, so d/d sigma and the
+    # logit path of d/dp are exactly 0) is compared on the scale of the feature gradient instead of its own
+    scale = np.linalg.norm(ra)
+    relz = lambda g, r: rel(g, r) if np.linalg.norm(r) > 1e-9 * scale else np.linalg.norm(g) / scale
+    errs = {"p": relz(gp, rp), "a": rel(ga, ra)}
     if check_sigma and cfg.get("use_gaussian_window", True):
-        errs["sigma"] = rel(gs, rs)
+        errs["sigma"] = relz(gs, rs)
     for k, e in errs.items():
         assert np.isfinite(e) and e < TOL[precision], (cfg["invariant"], precision, k, e, errs)
     return errs
@@ -73,3 +77,20 @@ def test_backward_shapes(cuda, D, H, C, O, Z, N, precision):
 def test_backward_no_window(cuda):
     cfg = make_cfg("rel_pos", use_window=False, freq=(0.5, 0.5))
     check(cuda, cfg, B=2, N=64, Z=8, precision="f32")
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_shape_sweep(cuda, case, pair_variant, bwd_variant):
+    """Seeded random shapes (ragged N and Z, every invariant, widths / heads / precisions mixed): outputs and latent gradients
+    against the oracle under all four combinations of forward / backward kernel variants."""
+    rng = np.random.default_rng(1000 + case)
+    inv = ["rel_pos_periodic", "latitude_periodic", "polar_periodic", "ponita", "abs_pos", "rel_pos", "norm_rel_pos", "ball",
+           "ball_lat"][case % 9]
+    D, H = [(64, 1), (64, 2), (128, 1), (128, 2), (64, 4)][int(rng.integers(5))]
+    if inv in ("ball", "ball_lat"):
+        D = 64
+        H = min(H, 2) if D == 64 and H == 4 else H
+    B, N, Z = int(rng.integers(1, 4)), int(rng.integers(1, 150)), int(rng.integers(1, 40))
+    precision = "f32" if case % 2 == 0 else "bf16"
+    cfg = make_cfg(inv, D=D, H=H, C=int(rng.integers(2, 20)), O=int(rng.integers(1, 5)), freq=(0.3, 0.6))
+    check(cuda, cfg, B=B, N=N, Z=Z, precision=precision, seed=2000 + case)
