@@ -155,3 +155,17 @@ def test_relu_masks_replay(cuda):
     assert not torch.equal(o2, o3)
     o4, _ = run(p)                              # the setting is consumed: the next pass is a plain one again
     assert torch.equal(o4, o0)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_weight_grads_random_shape_sweep(cuda, case):
+    """Seeded random shapes for the training path (ragged N / Z, invariants, widths, heads; fp32 kernels and, for the
+    odd cases, bf16 kernels with their permuted activation store)."""
+    rng = np.random.default_rng(3000 + case)
+    inv = ["rel_pos_periodic", "latitude_periodic", "ponita", "rel_pos", "norm_rel_pos", "ball", "polar_periodic", "abs_pos"][case]
+    D, H = [(64, 1), (64, 2), (128, 1), (128, 2), (64, 4)][int(rng.integers(5))]
+    if inv == "ball":
+        D, H = 64, min(H, 2)
+    B, N, Z = int(rng.integers(1, 4)), int(rng.integers(2, 120)), int(rng.integers(2, 30))
+    cfg = make_cfg(inv, D=D, H=H, C=int(rng.integers(2, 20)), O=int(rng.integers(1, 4)), freq=(0.3, 0.6))
+    check(cuda, cfg, B=B, N=N, Z=Z, precision="f32" if case % 2 == 0 else "bf16", seed=4000 + case)
