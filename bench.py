@@ -149,7 +149,8 @@ def roofline_leg(nef, params, coords, device, iters=20):
     return {"bound": "mfma", "kernel": "enf_pair_fwd_kernel", "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
             "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / peak, 4),
             "traffic": traffic, "launch_ms": round(ms, 4), "flops_per_launch": flops,
-            "note": "algorithmic (as-written) per-pair FLOPs; the kernel executes ~0.33x of them (exact folds, DESIGN.md)"}
+            "note": "algorithmic (as-written) per-pair FLOPs; the kernel executes ~0.33x of them (exact folds, DESIGN.md)"
+                    + ("" if bf16 else "; in f32 mode the fraction can therefore exceed 1 of the 157 TF fp32-MFMA peak")}
 
 
 def cpu_baseline_leg(seed=0):
