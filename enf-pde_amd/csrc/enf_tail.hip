@@ -10,6 +10,7 @@
 // then runs dX = W dY through the transposed panels and emits d(ybar) and
 // delta[n,h] = sum_d d(ybar)[n,h,d] * ybar[n,h,d]  (the softmax-backward row constant).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "enf_layout.h"
 #include "enf_device.h"
 
@@ -46,15 +47,85 @@ template <int D, int H, bool BF16> struct TailCfg {
   static constexpr int ST_G4 = PanelCfg<1, NT, BF16>::STAGE;      // gto4: out D, in 32
   static constexpr int ST_G0 = PanelCfg<KB, NTH, BF16>::STAGE;    // gto0: out HD, in D
   static constexpr int SMEM = 2 * STAGE_MAX + 4 * (2 * HD + 2 * D + 32);
+  static constexpr int SMEM3 = 3 * STAGE_MAX + 4 * (2 * HD + 2 * D + 32);      // LA2: three ring slots
 };
+
+// ---- LA2: a 3-slot ring with TWO stages in flight.  The tail's GEMM stages are short (0.25 us of MFMAs per 32 KB
+// stage) against ~1.1 us from LDS-DMA issue to landing, so with one stage in flight (panel_gemm) a small grid -- the fit
+// shape has 64 workgroups, one per CU -- spends its time waiting for weights.  Here stage s + 2 of the kernel's stage
+// stream is issued at the start of stage s; the end-of-stage wait lets that newest stage stay outstanding
+// (s_waitcnt vmcnt(its per-wave instruction count)) and only requires stage s + 1.  One barrier per stage as before:
+// a wave writes slot (s + 2) % 3 = (s - 1) % 3 only after every wave has left stage s - 1.
+// (Large grids keep the 2-slot kernel: two workgroups per CU hide the latency there and need the LDS.)
+template <int BYTES> struct La2Cnt { static constexpr int K = BYTES > 0 ? (BYTES / 1024) / NWAVES : 0; };
+template <int K> DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); }
+template <int BYTES> DEV void la2_issue(const Pipe& P, unsigned off, char* ring, int slot, int lane) {
+  stage_issue<BYTES>(P.rs, off, ring + slot * STAGE_MAX, P.wave, lane);
+}
+// panel descriptor for the stream: offset at run time, shape at compile time
+template <int KBIN, int MTOUT, bool BF16> struct Pan {
+  using C = PanelCfg<KBIN, MTOUT, BF16>;
+  static constexpr int SPP = C::SPP, STAGE = C::STAGE;
+};
+struct NoPan { static constexpr int SPP = 0, STAGE = 0; };
+
+// One stage step: issue the stage two ahead (own panel, else next panel N1, else the one after, N2), multiply, wait, barrier.
+template <int SP, int KBIN, int MTOUT, bool BF16, typename N1, typename N2, int INIT>
+DEV void la2_step(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned n1, unsigned n2,
+                  int lane, const float* bias) {
+  using C = PanelCfg<KBIN, MTOUT, BF16>;
+  constexpr int AHEAD = SP + 2 - C::SPP;          // < 0: own panel; 0.. : stage AHEAD of the following panels
+  const int slot2 = (P.cur + 2) % 3;
+  constexpr int ISSUED = AHEAD < 0 ? C::STAGE : (AHEAD < N1::SPP ? N1::STAGE : (AHEAD == N1::SPP && N1::SPP <= 1 ? N2::STAGE : 0));
+  if constexpr (AHEAD < 0) la2_issue<C::STAGE>(P, panel + (SP + 2) * C::STAGE, ring, slot2, lane);
+  else if constexpr (AHEAD < N1::SPP) la2_issue<N1::STAGE>(P, n1 + AHEAD * N1::STAGE, ring, slot2, lane);
+  else if constexpr (AHEAD == N1::SPP && N1::SPP <= 1 && N2::STAGE > 0) la2_issue<N2::STAGE>(P, n2, ring, slot2, lane);
+  gemm_stage<BF16, KBIN, C::MTS, INIT>(&acc[SP * C::MTS], F, ring + P.cur * STAGE_MAX, lane, bias + 16 * SP * C::MTS);
+  wait_vm<La2Cnt<ISSUED>::K>();
+  __syncthreads();
+  P.cur = (P.cur + 1) % 3;
+}
+template <int KBIN, int MTOUT, bool BF16, typename N1, typename N2, int INIT = INIT_ACC>
+DEV void panel_gemm_la2(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned n1,
+                        unsigned n2, int lane, const float* bias = nullptr) {
+  using C = PanelCfg<KBIN, MTOUT, BF16>;
+  static_assert(C::SPP <= 8, "unrolled by hand");
+#define LA2_STEP(SP_) if constexpr (C::SPP > SP_) la2_step<SP_, KBIN, MTOUT, BF16, N1, N2, INIT>(acc, F, P, ring, panel, n1, n2, lane, bias);
+  LA2_STEP(0) LA2_STEP(1) LA2_STEP(2) LA2_STEP(3) LA2_STEP(4) LA2_STEP(5) LA2_STEP(6) LA2_STEP(7)
+#undef LA2_STEP
+}
+// stream start: stage 0 and stage 1 (of the first panel A, or of the second panel B when A has one stage)
+template <typename A0, typename B0>
+DEV void la2_first(Pipe& P, char* ring, unsigned a, unsigned b, int wave, int lane) {
+  P.cur = 0;
+  P.wave = __builtin_amdgcn_readfirstlane(wave);
+  P.early = false;
+  la2_issue<A0::STAGE>(P, a, ring, 0, lane);
+  constexpr int S1 = A0::SPP > 1 ? A0::STAGE : B0::STAGE;
+  if constexpr (A0::SPP > 1) la2_issue<A0::STAGE>(P, a + A0::STAGE, ring, 1, lane);
+  else if constexpr (B0::STAGE > 0) la2_issue<B0::STAGE>(P, b, ring, 1, lane);
+  wait_vm<La2Cnt<S1>::K>();
+  __syncthreads();
+}
+// dispatch: LA2 or the 2-slot panel_gemm
+template <bool LA2, int KBIN, int MTOUT, bool BF16, typename N1, typename N2, int NEXT_BYTES>
+DEV void tail_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned n1, unsigned n2,
+                   int lane) {
+  if constexpr (LA2) panel_gemm_la2<KBIN, MTOUT, BF16, N1, N2>(acc, F, P, ring, panel, n1, n2, lane);
+  else panel_gemm<KBIN, MTOUT, BF16, NEXT_BYTES>(acc, F, P, ring, panel, n1, true, lane);
+}
 
 // Forward chain for this wave's 16 queries.  o4 = the (padded) 32 network outputs.
 // SAVE: stash pre-activations + LN stats to `act` (row per query) for the backward chain.
-template <int D, int H, bool BF16, bool SAVE, int NEXT_BYTES>
+// NX1 / NX2 (Pan<..> or NoPan) + next / next2: the two panels that follow the forward chain (the backward chain's first
+// two, or nothing); the 2-slot pipeline only uses the first stage of NX1.
+template <int D, int H, bool BF16, bool SAVE, bool LA2, typename NX1, typename NX2>
 DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLayout& L, const float* cst, Pipe& P,
-                      char* ring, unsigned next, int lane, int quad, float inv_hd) {
+                      char* ring, unsigned next, unsigned next2, int lane, int quad, float inv_hd) {
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
+  using PTB = Pan<KBH, NTH, BF16>; using PO0 = Pan<KBH, NT, BF16>; using PO2 = Pan<KB, NT, BF16>; using PO4 = Pan<KB, 2, BF16>;
+  constexpr int NEXT_BYTES = NX1::STAGE > 0 ? NX1::STAGE : 1024;
   const float* c_bB = cst, *c_bF1 = cst + HD, *c_bO0 = cst + 2 * HD, *c_bO2 = cst + 2 * HD + D, *c_bO4 = cst + 2 * HD + 2 * D;
   Frags<BF16, KBH> FH;
   f32x4 a[NTH];
@@ -62,7 +133,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
   make_frags<BF16, KBH>(FH, a);
 #pragma unroll
   for (int t = 0; t < NTH; ++t) a[t] = rowvec(c_bB, t, quad);
-  panel_gemm<KBH, NTH, BF16, T::ST_TB>(a, FH, P, ring, (unsigned)L.atb, (unsigned)L.atf1, true, lane);
+  tail_gemm<LA2, KBH, NTH, BF16, PTB, PO0, T::ST_TB>(a, FH, P, ring, (unsigned)L.atb, (unsigned)L.atf1, (unsigned)L.ato0, lane);
   if (SAVE) store_rows<NTH>(a, act, quad);
 #pragma unroll
   for (int t = 0; t < NTH; ++t)
@@ -78,7 +149,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
   make_frags<BF16, KBH>(FH, a);
 #pragma unroll
   for (int t = 0; t < NTH; ++t) a[t] = rowvec(c_bF1, t, quad);
-  panel_gemm<KBH, NTH, BF16, T::ST_O0>(a, FH, P, ring, (unsigned)L.atf1, (unsigned)L.ato0, true, lane);
+  tail_gemm<LA2, KBH, NTH, BF16, PO0, PO2, T::ST_O0>(a, FH, P, ring, (unsigned)L.atf1, (unsigned)L.ato0, (unsigned)L.ato2, lane);
   if (SAVE) store_rows<NTH>(a, act + HD, quad);
 #pragma unroll
   for (int t = 0; t < NTH; ++t)
@@ -88,7 +159,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
   f32x4 c[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) c[t] = rowvec(c_bO0, t, quad);
-  panel_gemm<KBH, NT, BF16, T::ST_O2>(c, FH, P, ring, (unsigned)L.ato0, (unsigned)L.ato2, true, lane);
+  tail_gemm<LA2, KBH, NT, BF16, PO2, PO4, T::ST_O2>(c, FH, P, ring, (unsigned)L.ato0, (unsigned)L.ato2, (unsigned)L.ato4, lane);
   if (SAVE) store_rows<NT>(c, act + 2 * HD, quad);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -98,7 +169,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
   make_frags<BF16, KB>(FD, c);
 #pragma unroll
   for (int t = 0; t < NT; ++t) c[t] = rowvec(c_bO2, t, quad);
-  panel_gemm<KB, NT, BF16, T::ST_O4>(c, FD, P, ring, (unsigned)L.ato2, (unsigned)L.ato4, true, lane);
+  tail_gemm<LA2, KB, NT, BF16, PO4, NX1, T::ST_O4>(c, FD, P, ring, (unsigned)L.ato2, (unsigned)L.ato4, next, lane);
   if (SAVE) store_rows<NT>(c, act + 2 * HD + D, quad);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -107,7 +178,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
   make_frags<BF16, KB>(FD, c);
   o4[0] = rowvec(c_bO4, 0, quad);
   o4[1] = rowvec(c_bO4, 1, quad);
-  panel_gemm<KB, 2, BF16, NEXT_BYTES>(o4, FD, P, ring, (unsigned)L.ato4, next, true, lane);
+  tail_gemm<LA2, KB, 2, BF16, NX1, NX2, NEXT_BYTES>(o4, FD, P, ring, (unsigned)L.ato4, next, next2, lane);
 }
 
 template <int D, int H, bool BF16>
@@ -119,12 +190,12 @@ DEV void tail_consts(float* cst, const char* blob, const EnfLayout& L, int tid) 
   for (int i = tid; i < 32; i += NTHREADS) cst[2 * HD + 2 * D + i] = G(L.bO4)[i];
 }
 
-template <int D, int H, bool BF16>
+template <int D, int H, bool BF16, bool LA2>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   using T = TailCfg<D, H, BF16>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
-  float* cst = reinterpret_cast<float*>(smem + 2 * STAGE_MAX);
+  float* cst = reinterpret_cast<float*>(smem + (LA2 ? 3 : 2) * STAGE_MAX);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, quad = lane >> 4;
   const int q0 = blockIdx.x * (16 * NWAVES) + wave * 16;
   const int qi = min(q0 + col, A.NQ - 1);
@@ -132,9 +203,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   Pipe P;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
   P.rs2 = P.rs;
-  first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
+  if constexpr (LA2) {
+    __syncthreads();                                   // the LDS constants, for waves that run ahead of the first stage barrier
+    la2_first<Pan<T::KBH, T::NTH, BF16>, Pan<T::KBH, T::NTH, BF16>>(P, ring, (unsigned)A.L.atb, (unsigned)A.L.atf1, wave, lane);
+  } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
-  tail_forward<D, H, BF16, false, 1024>(o4, A.ybar + (size_t)qi * T::HD, nullptr, A.L, cst, P, ring, NO_STAGE, lane, quad, A.inv_hd);
+  tail_forward<D, H, BF16, false, LA2, NoPan, NoPan>(o4, A.ybar + (size_t)qi * T::HD, nullptr, A.L, cst, P, ring, NO_STAGE, NO_STAGE,
+                                                     lane, quad, A.inv_hd);
   if (q0 + col < A.NQ) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -146,13 +221,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   }
 }
 
-template <int D, int H, bool BF16>
+template <int D, int H, bool BF16, bool LA2>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
+  using PG4 = Pan<1, NT, BF16>; using PG2 = Pan<KB, NT, BF16>; using PG0 = Pan<KB, NTH, BF16>; using PGH = Pan<KBH, NTH, BF16>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
-  float* cst = reinterpret_cast<float*>(smem + 2 * STAGE_MAX);
+  float* cst = reinterpret_cast<float*>(smem + (LA2 ? 3 : 2) * STAGE_MAX);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, quad = lane >> 4;
   const int q0 = blockIdx.x * (16 * NWAVES) + wave * 16;
   const bool qvalid = q0 + col < A.NQ;
@@ -164,9 +240,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   Pipe P;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
   P.rs2 = P.rs;
-  first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
+  if constexpr (LA2) {
+    __syncthreads();
+    la2_first<PGH, PGH>(P, ring, (unsigned)A.L.atb, (unsigned)A.L.atf1, wave, lane);
+  } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
-  tail_forward<D, H, BF16, true, T::ST_G4>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, lane, quad, A.inv_hd);
+  tail_forward<D, H, BF16, true, LA2, PG4, PG2>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, lane, quad,
+                                                A.inv_hd);
   // the pre-activations this lane stored are re-read by this lane only (same addresses)
 
   // ---- backward chain
@@ -182,7 +262,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   make_frags<BF16, 1>(F1, g0);
   f32x4 c[NT];
   zero_tiles<NT>(c);
-  panel_gemm<1, NT, BF16, T::ST_O2>(c, F1, P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, true, lane);          // d g4
+  tail_gemm<LA2, 1, NT, BF16, PG2, PG0, T::ST_O2>(c, F1, P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, (unsigned)A.L.gto0, lane);   // d g4
   {
     f32x4 pre[NT];
     load_rows<NT>(pre, act + 2 * HD + D, quad);
@@ -194,7 +274,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   Frags<BF16, KB> FD;
   make_frags<BF16, KB>(FD, c);
   zero_tiles<NT>(c);
-  panel_gemm<KB, NT, BF16, T::ST_G0>(c, FD, P, ring, (unsigned)A.L.gto2, (unsigned)A.L.gto0, true, lane);         // d g3
+  tail_gemm<LA2, KB, NT, BF16, PG0, PGH, T::ST_G0>(c, FD, P, ring, (unsigned)A.L.gto2, (unsigned)A.L.gto0, (unsigned)A.L.gtf1, lane);  // d g3
   {
     f32x4 pre[NT];
     load_rows<NT>(pre, act + 2 * HD, quad);
@@ -206,7 +286,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   make_frags<BF16, KB>(FD, c);
   f32x4 a[NTH];
   zero_tiles<NTH>(a);
-  panel_gemm<KB, NTH, BF16, T::ST_TB>(a, FD, P, ring, (unsigned)A.L.gto0, (unsigned)A.L.gtf1, true, lane);        // d g2
+  tail_gemm<LA2, KB, NTH, BF16, PGH, PGH, T::ST_TB>(a, FD, P, ring, (unsigned)A.L.gto0, (unsigned)A.L.gtf1, (unsigned)A.L.gtb, lane);  // d g2
   {
     f32x4 pre[NTH];
     load_rows<NTH>(pre, act + HD, quad);
@@ -218,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   Frags<BF16, KBH> FH;
   make_frags<BF16, KBH>(FH, a);
   zero_tiles<NTH>(a);
-  panel_gemm<KBH, NTH, BF16, T::ST_TB>(a, FH, P, ring, (unsigned)A.L.gtf1, (unsigned)A.L.gtb, true, lane);        // d n
+  tail_gemm<LA2, KBH, NTH, BF16, PGH, NoPan, T::ST_TB>(a, FH, P, ring, (unsigned)A.L.gtf1, (unsigned)A.L.gtb, NO_STAGE, lane);          // d n
   {
     // LayerNorm backward + gelu backward on a_B
     f32x4 pre[NTH];
@@ -243,7 +323,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   }
   make_frags<BF16, KBH>(FH, a);
   zero_tiles<NTH>(a);
-  panel_gemm<KBH, NTH, BF16, 1024>(a, FH, P, ring, (unsigned)A.L.gtb, NO_STAGE, true, lane);                     // d ybar
+  tail_gemm<LA2, KBH, NTH, BF16, NoPan, NoPan, 1024>(a, FH, P, ring, (unsigned)A.L.gtb, NO_STAGE, NO_STAGE, lane);                       // d ybar
   f32x4 y[NTH];
   load_rows<NTH>(y, yrow, quad);
 #pragma unroll
@@ -262,16 +342,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
 template <int D, int H, bool BF16>
 static int launch_tail(const TailArgs& A, bool bwd, hipStream_t st) {
   using T = TailCfg<D, H, BF16>;
-  static bool attr_set[2] = {false, false};
-  const void* kern = bwd ? reinterpret_cast<const void*>(enf_tail_bwd_kernel<D, H, BF16>)
-                         : reinterpret_cast<const void*>(enf_tail_fwd_kernel<D, H, BF16>);
-  if (!attr_set[bwd]) {
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM) != hipSuccess) return ENF_ELAUNCH;
-    attr_set[bwd] = true;
-  }
   dim3 grid((A.NQ + 16 * NWAVES - 1) / (16 * NWAVES));
-  if (bwd) hipLaunchKernelGGL((enf_tail_bwd_kernel<D, H, BF16>), grid, dim3(NTHREADS), T::SMEM, st, A);
-  else hipLaunchKernelGGL((enf_tail_fwd_kernel<D, H, BF16>), grid, dim3(NTHREADS), T::SMEM, st, A);
+  // few workgroups (at most one per CU): the deeper weight pipeline (LA2) instead of a second workgroup per CU
+  static int la2_mode = -1;
+  if (la2_mode < 0) { const char* e = getenv("ENF_TAIL_LA2"); la2_mode = e ? (e[0] == '0' ? 0 : 1) : 2; }
+  const bool la2 = la2_mode == 2 ? grid.x <= 256 : la2_mode == 1;
+  static bool attr_set[2][2] = {{false, false}, {false, false}};
+  const void* kern = la2 ? (bwd ? reinterpret_cast<const void*>(enf_tail_bwd_kernel<D, H, BF16, true>)
+                                : reinterpret_cast<const void*>(enf_tail_fwd_kernel<D, H, BF16, true>))
+                         : (bwd ? reinterpret_cast<const void*>(enf_tail_bwd_kernel<D, H, BF16, false>)
+                                : reinterpret_cast<const void*>(enf_tail_fwd_kernel<D, H, BF16, false>));
+  const int smem = la2 ? T::SMEM3 : T::SMEM;
+  if (!attr_set[la2][bwd]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return ENF_ELAUNCH;
+    attr_set[la2][bwd] = true;
+  }
+  if (la2) {
+    if (bwd) hipLaunchKernelGGL((enf_tail_bwd_kernel<D, H, BF16, true>), grid, dim3(NTHREADS), smem, st, A);
+    else hipLaunchKernelGGL((enf_tail_fwd_kernel<D, H, BF16, true>), grid, dim3(NTHREADS), smem, st, A);
+  } else {
+    if (bwd) hipLaunchKernelGGL((enf_tail_bwd_kernel<D, H, BF16, false>), grid, dim3(NTHREADS), smem, st, A);
+    else hipLaunchKernelGGL((enf_tail_fwd_kernel<D, H, BF16, false>), grid, dim3(NTHREADS), smem, st, A);
+  }
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
