@@ -15,7 +15,7 @@ int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const flo
                         const float*, const float*, float*, void* const*, const char*, const float*, float*, hipStream_t);
 int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
 int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
-                    int, hipStream_t);
+                    int, int, hipStream_t);
 }
 
 extern "C" int enf_abi_version(void) { return ENF_ABI_VERSION; }
@@ -94,7 +94,10 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
       (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
                                 zf ? ws + W.wzu : nullptr, (stages & ENF_STAGE_FOLD) != 0, (stages & ENF_STAGE_PAIR) != 0, st)))
     return rc;
-  if ((stages & ENF_STAGE_TAIL) && (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, nullptr, 0, st))) return rc;
+  const bool tsave = (stages & ENF_STAGE_TAIL_SAVE) != 0;      // stash the tail's pre-activations for the backward that follows
+  if ((stages & ENF_STAGE_TAIL) &&
+      (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, tsave ? F(W.tail_act) : nullptr, 0, tsave ? 1 : 0, st)))
+    return rc;
   return ENF_OK;
 }
 
@@ -168,7 +171,8 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
       if (hipEventRecord(side->join, side->s) != hipSuccess) return ENF_ELAUNCH;
     } else if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, st))) return rc;
   }
-  if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, st))) return rc;
+  const bool treuse = (flags & ENF_BWD_REUSE_TAIL) && (flags & ENF_BWD_REUSE_PROLOGUE);
+  if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, treuse ? 1 : 0, st))) return rc;
   if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
   if (zb && side) {
     std::lock_guard<std::mutex> lk(side->mu);

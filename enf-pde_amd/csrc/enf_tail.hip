@@ -190,7 +190,7 @@ DEV void tail_consts(float* cst, const char* blob, const EnfLayout& L, int tid) 
   for (int i = tid; i < 32; i += NTHREADS) cst[2 * HD + 2 * D + i] = G(L.bO4)[i];
 }
 
-template <int D, int H, bool BF16, bool LA2>
+template <int D, int H, bool BF16, bool LA2, bool SAVE>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   using T = TailCfg<D, H, BF16>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,8 +208,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
     la2_first<Pan<T::KBH, T::NTH, BF16>, Pan<T::KBH, T::NTH, BF16>>(P, ring, (unsigned)A.L.atb, (unsigned)A.L.atf1, wave, lane);
   } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
-  tail_forward<D, H, BF16, false, LA2, NoPan, NoPan>(o4, A.ybar + (size_t)qi * T::HD, nullptr, A.L, cst, P, ring, NO_STAGE, NO_STAGE,
-                                                     lane, quad, A.inv_hd);
+  // SAVE: the pre-activations go to the workspace so that the backward that follows need not recompute this chain
+  tail_forward<D, H, BF16, SAVE, LA2, NoPan, NoPan>(o4, A.ybar + (size_t)qi * T::HD, SAVE ? A.act + (size_t)qi * T::ACT : nullptr, A.L,
+                                                    cst, P, ring, NO_STAGE, NO_STAGE, lane, quad, A.inv_hd);
   if (q0 + col < A.NQ) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   }
 }
 
-template <int D, int H, bool BF16, bool LA2>
+template <int D, int H, bool BF16, bool LA2, bool RECOMP>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
@@ -240,13 +241,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   Pipe P;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
   P.rs2 = P.rs;
-  if constexpr (LA2) {
-    __syncthreads();
-    la2_first<PGH, PGH>(P, ring, (unsigned)A.L.atb, (unsigned)A.L.atf1, wave, lane);
-  } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
-  f32x4 o4[2];
-  tail_forward<D, H, BF16, true, LA2, PG4, PG2>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, lane, quad,
-                                                A.inv_hd);
+  if constexpr (RECOMP) {
+    if constexpr (LA2) {
+      __syncthreads();
+      la2_first<PGH, PGH>(P, ring, (unsigned)A.L.atb, (unsigned)A.L.atf1, wave, lane);
+    } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
+    f32x4 o4[2];
+    tail_forward<D, H, BF16, true, LA2, PG4, PG2>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, lane, quad,
+                                                  A.inv_hd);
+  } else {      // the forward of this step stashed the pre-activations (enf_tail_fwd_kernel<.., SAVE>): start at the backward chain
+    if constexpr (LA2) {
+      __syncthreads();
+      la2_first<PG4, PG2>(P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, wave, lane);
+    } else first_stage<T::ST_G4>(P, ring, (unsigned)A.L.gto4, wave, lane);
+  }
   // the pre-activations this lane stored are re-read by this lane only (same addresses)
 
   // ---- backward chain
@@ -340,41 +348,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
 }
 
 template <int D, int H, bool BF16>
-static int launch_tail(const TailArgs& A, bool bwd, hipStream_t st) {
+static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
   using T = TailCfg<D, H, BF16>;
   dim3 grid((A.NQ + 16 * NWAVES - 1) / (16 * NWAVES));
   // few workgroups (at most one per CU): the deeper weight pipeline (LA2) instead of a second workgroup per CU
   static int la2_mode = -1;
   if (la2_mode < 0) { const char* e = getenv("ENF_TAIL_LA2"); la2_mode = e ? (e[0] == '0' ? 0 : 1) : 2; }
   const bool la2 = la2_mode == 2 ? grid.x <= 256 : la2_mode == 1;
-  static bool attr_set[2][2] = {{false, false}, {false, false}};
-  const void* kern = la2 ? (bwd ? reinterpret_cast<const void*>(enf_tail_bwd_kernel<D, H, BF16, true>)
-                                : reinterpret_cast<const void*>(enf_tail_fwd_kernel<D, H, BF16, true>))
-                         : (bwd ? reinterpret_cast<const void*>(enf_tail_bwd_kernel<D, H, BF16, false>)
-                                : reinterpret_cast<const void*>(enf_tail_fwd_kernel<D, H, BF16, false>));
-  const int smem = la2 ? T::SMEM3 : T::SMEM;
-  if (!attr_set[la2][bwd]) {
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return ENF_ELAUNCH;
-    attr_set[la2][bwd] = true;
+  // opt: forward -> stash the pre-activations (SAVE); backward -> they are stashed, skip the recompute
+  static bool attr_done[2][2][2] = {};       // [bwd][la2][opt] (this function is one instantiation per D, H, BF16)
+  auto go = [&](void (*kern_ptr)(TailArgs)) -> int {
+    const int smem = la2 ? T::SMEM3 : T::SMEM;
+    if (!attr_done[bwd][la2][opt]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        return ENF_ELAUNCH;
+      attr_done[bwd][la2][opt] = true;
+    }
+    hipLaunchKernelGGL(kern_ptr, grid, dim3(NTHREADS), smem, st, A);
+    return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+  };
+  if (bwd) {
+    if (la2) return opt ? go(enf_tail_bwd_kernel<D, H, BF16, true, false>) : go(enf_tail_bwd_kernel<D, H, BF16, true, true>);
+    return opt ? go(enf_tail_bwd_kernel<D, H, BF16, false, false>) : go(enf_tail_bwd_kernel<D, H, BF16, false, true>);
   }
-  if (la2) {
-    if (bwd) hipLaunchKernelGGL((enf_tail_bwd_kernel<D, H, BF16, true>), grid, dim3(NTHREADS), smem, st, A);
-    else hipLaunchKernelGGL((enf_tail_fwd_kernel<D, H, BF16, true>), grid, dim3(NTHREADS), smem, st, A);
-  } else {
-    if (bwd) hipLaunchKernelGGL((enf_tail_bwd_kernel<D, H, BF16, false>), grid, dim3(NTHREADS), smem, st, A);
-    else hipLaunchKernelGGL((enf_tail_fwd_kernel<D, H, BF16, false>), grid, dim3(NTHREADS), smem, st, A);
-  }
-  return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
+  if (la2) return opt ? go(enf_tail_fwd_kernel<D, H, BF16, true, true>) : go(enf_tail_fwd_kernel<D, H, BF16, true, false>);
+  return opt ? go(enf_tail_fwd_kernel<D, H, BF16, false, true>) : go(enf_tail_fwd_kernel<D, H, BF16, false, false>);
 }
 
 extern "C" int enf_launch_tail(const EnfDims& m, const EnfLayout& L, const char* blob, const float* ybar, float* out,
-                               const float* dout, float* dybar, float* delta, float* act, int bwd, hipStream_t st) {
+                               const float* dout, float* dybar, float* delta, float* act, int bwd, int opt, hipStream_t st) {
   if (m.OB != 1) return ENF_EUNSUPPORTED;
   TailArgs A;
   A.ybar = ybar; A.blob = blob; A.L = L; A.out = out; A.dout = dout; A.dybar = dybar; A.delta = delta; A.act = act;
   A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.Ht * m.Dt);
 #define ENF_CASE(DD, HH)                                                                   \
-  if (m.D == DD && m.H == HH) return m.bf16 ? launch_tail<DD, HH, true>(A, bwd != 0, st) : launch_tail<DD, HH, false>(A, bwd != 0, st);
+  if (m.D == DD && m.H == HH) return m.bf16 ? launch_tail<DD, HH, true>(A, bwd != 0, opt != 0, st) : launch_tail<DD, HH, false>(A, bwd != 0, opt != 0, st);
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)

@@ -95,8 +95,10 @@ class _EnfFunction(torch.autograd.Function):
         lse = torch.empty((B, N, model._Hp), device=dev, dtype=torch.float32)
         ws = model._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.enf_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
-                                   _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), st))
+        # a backward follows when an input needs a gradient: stash the tail's pre-activations for it (ENF_STAGE_TAIL_SAVE)
+        ctx.tail_saved = any(ctx.needs_input_grad[1:4])
+        _lib.check(lib.enf_forward_stages(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
+                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | (16 if ctx.tail_saved else 0), st))
         ctx.ws_tag = model._ws_touch(ws)      # backward may reuse the latent table if nothing else used the workspace
         ctx.model = model
         ctx.has_sigma = sigma is not None
@@ -122,6 +124,8 @@ class _EnfFunction(torch.autograd.Function):
         ws = model._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         reuse = 1 if model._ws_tag(ws) == ctx.ws_tag else 0          # ENF_BWD_REUSE_PROLOGUE
+        if reuse and ctx.tail_saved:
+            reuse |= 2                                               # ENF_BWD_REUSE_TAIL
         _lib.check(lib.enf_backward_latents_ex(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(p_), _ptr(a_), _ptr(sigma),
                                                _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
                                                _ptr(dsig), _ptr(ws), ws.numel(), reuse, st))
@@ -418,8 +422,8 @@ class EquivariantCrossAttentionNeF:
         lse = torch.empty((B, N, self._Hp), device=dev, dtype=torch.float32)
         ws = self._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.enf_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
-                                   _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), st))
+        _lib.check(lib.enf_forward_stages(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
+                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16, st))   # + ENF_STAGE_TAIL_SAVE
         tgt = target.float().contiguous()
         if tgt.shape != out.shape:
             raise AssertionError(f"target has shape {tuple(tgt.shape)}, expected {tuple(out.shape)}")
@@ -430,6 +434,6 @@ class EquivariantCrossAttentionNeF:
         dsig = torch.empty((B, Z, 1), device=dev, dtype=torch.float32)
         _lib.check(lib.enf_backward_latents_ex(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_),
                                                _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
-                                               _ptr(dsig), _ptr(ws), ws.numel(), 1, st))       # the latent table is the forward's
+                                               _ptr(dsig), _ptr(ws), ws.numel(), 1 | 2, st))   # latent table and tail stash are the forward's
         self._ws_touch(ws)
         return loss, dp, da, (dsig if sigma is not None else None)

@@ -128,6 +128,8 @@ int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float
 #define ENF_STAGE_TAIL 4u
 #define ENF_STAGE_FOLD 8u      /* enf_wz_kernel: per-latent folded matrices of the z-fold pair variant (no-op otherwise);
                                   runs between PROLOGUE and PAIR, PAIR alone reuses what the workspace holds */
+#define ENF_STAGE_TAIL_SAVE 16u /* with ENF_STAGE_TAIL: stash the tail's pre-activations in the workspace; the backward
+                                  that follows on the untouched workspace (ENF_BWD_REUSE_TAIL) then skips their recompute */
 int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
                        const float* sigma, const void* packed, float* out, float* ybar, float* lse,
                        void* workspace, size_t workspace_bytes, unsigned stages, void* stream);
@@ -142,6 +144,9 @@ int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, co
 /* flags: ENF_BWD_REUSE_PROLOGUE = the workspace still holds the latent table of the enf_forward call with the same
  * (p, a, sigma, weights) -- nothing else has used it since -- so the prologue is not recomputed. */
 #define ENF_BWD_REUSE_PROLOGUE 1u
+/* ENF_BWD_REUSE_TAIL (with ENF_BWD_REUSE_PROLOGUE): that forward also ran with ENF_STAGE_TAIL_SAVE: the tail backward
+ * reads the stashed pre-activations instead of recomputing the tail's forward chain (half of its GEMM stages). */
+#define ENF_BWD_REUSE_TAIL 2u
 int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p,
                          const float* a, const float* sigma, const void* packed, const float* ybar,
                          const float* lse, const float* dout, float* dp, float* da, float* dsigma,
