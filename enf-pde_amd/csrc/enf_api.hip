@@ -71,6 +71,42 @@ extern "C" size_t enf_workspace_bytes(const EnfDesc* d) {
   return enf_workspace(enf_dims(d)).total;
 }
 
+// One side stream per process for work that can overlap the caller's stream (created on first use; ENF_SIDE_STREAM=0
+// disables it).  Fork / join is by events, so the caller's stream order is preserved; the mutex keeps concurrent host
+// threads from interleaving their record / wait pairs on the shared events.
+struct SideStream { hipStream_t s; hipEvent_t fork, join; std::mutex mu; bool pending = false; };
+static SideStream* side_stream() {
+  static SideStream* S = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* e = getenv("ENF_SIDE_STREAM");
+    if (!(e && e[0] == '0')) {
+      SideStream* t = new SideStream();
+      if (hipStreamCreateWithFlags(&t->s, hipStreamNonBlocking) == hipSuccess &&
+          hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&t->join, hipEventDisableTiming) == hipSuccess)
+        S = t;
+      else
+        delete t;
+    }
+  }
+  return S;
+}
+
+// join side-stream work left pending by an earlier ENF_STAGE_PREPARE_BWD (no matching backward came) before `st`
+// touches the workspace regions it writes
+static int side_join_pending(hipStream_t st) {
+  SideStream* side = side_stream();
+  if (!side) return 0;
+  std::lock_guard<std::mutex> lk(side->mu);
+  if (side->pending) {
+    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ENF_ELAUNCH;
+    side->pending = false;
+  }
+  return 0;
+}
+
 extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
                                   const float* sigma, const void* packed, float* out, float* ybar, float* lse,
                                   void* workspace, size_t workspace_bytes, unsigned stages, void* stream) {
@@ -89,11 +125,25 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
   float* yb = ybar ? ybar : F(W.ybar);
   const bool zf = enf_use_zfold(m);
   float* ls = lse ? lse : F(W.lse);
+  if ((rc = side_join_pending(st))) return rc;
   if ((stages & ENF_STAGE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
   if ((stages & (ENF_STAGE_PAIR | ENF_STAGE_FOLD)) &&
       (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
                                 zf ? ws + W.wzu : nullptr, (stages & ENF_STAGE_FOLD) != 0, (stages & ENF_STAGE_PAIR) != 0, st)))
     return rc;
+  if ((stages & ENF_STAGE_PREPARE_BWD) && enf_use_zfold_bwd(m)) {
+    // what the backward needs from the latent table alone -- its per-latent folded matrices, the zeroed gradient table --
+    // starts on the side stream behind the pair kernel, beside the tail, the caller's loss and the tail backward
+    SideStream* side = side_stream();
+    if (side) {
+      std::lock_guard<std::mutex> lk(side->mu);
+      if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
+      if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, side->s))) return rc;
+      if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), side->s) != hipSuccess) return ENF_ELAUNCH;
+      if (hipEventRecord(side->join, side->s) != hipSuccess) return ENF_ELAUNCH;
+      side->pending = true;
+    }
+  }
   const bool tsave = (stages & ENF_STAGE_TAIL_SAVE) != 0;      // stash the tail's pre-activations for the backward that follows
   if ((stages & ENF_STAGE_TAIL) &&
       (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, tsave ? F(W.tail_act) : nullptr, 0, tsave ? 1 : 0, st)))
@@ -106,29 +156,6 @@ extern "C" int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, 
                            size_t workspace_bytes, void* stream) {
   return enf_forward_stages(d, x, x_bstride, p, a, sigma, packed, out, ybar, lse, workspace, workspace_bytes,
                             ENF_STAGE_PROLOGUE | ENF_STAGE_FOLD | ENF_STAGE_PAIR | ENF_STAGE_TAIL, stream);
-}
-
-// One side stream per process for work that can overlap the caller's stream (created on first use; ENF_SIDE_STREAM=0
-// disables it).  Fork / join is by events, so the caller's stream order is preserved; the mutex keeps concurrent host
-// threads from interleaving their record / wait pairs on the shared events.
-struct SideStream { hipStream_t s; hipEvent_t fork, join; std::mutex mu; };
-static SideStream* side_stream() {
-  static SideStream* S = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    const char* e = getenv("ENF_SIDE_STREAM");
-    if (!(e && e[0] == '0')) {
-      SideStream* t = new SideStream();
-      if (hipStreamCreateWithFlags(&t->s, hipStreamNonBlocking) == hipSuccess &&
-          hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess &&
-          hipEventCreateWithFlags(&t->join, hipEventDisableTiming) == hipSuccess)
-        S = t;
-      else
-        delete t;
-    }
-  }
-  return S;
 }
 
 extern "C" int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
@@ -163,7 +190,13 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
   // (fork / join by events) beside the tail backward instead of in front of the pair kernel
   const bool zb = enf_use_zfold_bwd(m);
   SideStream* side = zb ? side_stream() : nullptr;
-  if (zb) {
+  bool prepared = false;
+  if (zb && side && (flags & ENF_BWD_REUSE_PREPARED) && (flags & ENF_BWD_REUSE_PROLOGUE)) {
+    std::lock_guard<std::mutex> lk(side->mu);
+    prepared = side->pending;          // launched by the matching forward (ENF_STAGE_PREPARE_BWD)
+  }
+  if (!prepared && (rc = side_join_pending(st))) return rc;
+  if (zb && !prepared) {
     if (side) {
       std::lock_guard<std::mutex> lk(side->mu);
       if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
@@ -173,10 +206,11 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
   }
   const bool treuse = (flags & ENF_BWD_REUSE_TAIL) && (flags & ENF_BWD_REUSE_PROLOGUE);
   if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, treuse ? 1 : 0, st))) return rc;
-  if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
+  if (!prepared && hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
   if (zb && side) {
     std::lock_guard<std::mutex> lk(side->mu);
     if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ENF_ELAUNCH;
+    side->pending = false;
   }
   if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr,
                                 zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, nullptr, st))) return rc;

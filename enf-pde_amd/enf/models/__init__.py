@@ -19,6 +19,7 @@ from . import _pad
 
 __all__ = ["EquivariantCrossAttentionNeF", "TENSOR_PATHS", "tensor_paths"]
 
+_PREP = 0 if __import__("os").environ.get("ENF_PREPARE_BWD") == "0" else 32     # ENF_STAGE_PREPARE_BWD in the fused inner step (A/B switch)
 _BLK = "cross_attention_blocks_0"
 # ENF_W_* order of include/enf_hip.h -> path in the Flax parameter tree
 TENSOR_PATHS = [
@@ -423,7 +424,7 @@ class EquivariantCrossAttentionNeF:
         ws = self._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.enf_forward_stages(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
-                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16, st))   # + ENF_STAGE_TAIL_SAVE
+                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16 | _PREP, st))   # + TAIL_SAVE (+ PREPARE_BWD)
         tgt = target.float().contiguous()
         if tgt.shape != out.shape:
             raise AssertionError(f"target has shape {tuple(tgt.shape)}, expected {tuple(out.shape)}")
@@ -434,6 +435,6 @@ class EquivariantCrossAttentionNeF:
         dsig = torch.empty((B, Z, 1), device=dev, dtype=torch.float32)
         _lib.check(lib.enf_backward_latents_ex(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_),
                                                _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
-                                               _ptr(dsig), _ptr(ws), ws.numel(), 1 | 2, st))   # latent table and tail stash are the forward's
+                                               _ptr(dsig), _ptr(ws), ws.numel(), 1 | 2 | (_PREP >> 3), st))   # latent table, tail stash (, side work) are the forward's
         self._ws_touch(ws)
         return loss, dp, da, (dsig if sigma is not None else None)

@@ -130,6 +130,9 @@ int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float
                                   runs between PROLOGUE and PAIR, PAIR alone reuses what the workspace holds */
 #define ENF_STAGE_TAIL_SAVE 16u /* with ENF_STAGE_TAIL: stash the tail's pre-activations in the workspace; the backward
                                   that follows on the untouched workspace (ENF_BWD_REUSE_TAIL) then skips their recompute */
+#define ENF_STAGE_PREPARE_BWD 32u /* a backward on the same inputs follows: what it needs from the latent table alone (its
+                                  per-latent folded matrices, the zeroed gradient table) starts on the library's side stream
+                                  behind the pair kernel; pass ENF_BWD_REUSE_PREPARED to that backward */
 int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
                        const float* sigma, const void* packed, float* out, float* ybar, float* lse,
                        void* workspace, size_t workspace_bytes, unsigned stages, void* stream);
@@ -147,6 +150,9 @@ int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, co
 /* ENF_BWD_REUSE_TAIL (with ENF_BWD_REUSE_PROLOGUE): that forward also ran with ENF_STAGE_TAIL_SAVE: the tail backward
  * reads the stashed pre-activations instead of recomputing the tail's forward chain (half of its GEMM stages). */
 #define ENF_BWD_REUSE_TAIL 2u
+/* ENF_BWD_REUSE_PREPARED (with ENF_BWD_REUSE_PROLOGUE): that forward ran with ENF_STAGE_PREPARE_BWD: join its side-stream
+ * work instead of repeating it (ignored when nothing is pending). */
+#define ENF_BWD_REUSE_PREPARED 4u
 int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p,
                          const float* a, const float* sigma, const void* packed, const float* ybar,
                          const float* lse, const float* dout, float* dp, float* da, float* dsigma,
