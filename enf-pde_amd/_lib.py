@@ -17,7 +17,7 @@ EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invarian
            "enf_backward_latents", "enf_backward_latents_ex", "enf_forward_stages", "enf_lt_layout", "enf_lt_layout_ext", "enf_pack_pair", "enf_pair_forward",
            "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_set_zfold", "enf_set_zfold_bwd", "enf_mse_value_grad",
            "enf_ode_conv_forward", "enf_ode_conv_backward_basis", "enf_ode_poly_num_features", "enf_ode_poly_forward",
-           "enf_ode_poly_backward", "enf_relu_mask_bytes", "enf_set_relu_masks"]
+           "enf_ode_poly_backward", "enf_relu_mask_bytes", "enf_set_relu_masks", "enf_meta_sgd_update"]
 ENF_NUM_PAIR_TENSORS = 12          # ENF_P_* of include/enf_hip.h
 (ENF_S_EQ, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0) = range(8)
 
@@ -31,6 +31,15 @@ class EnfDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("B", "N", "Z", "H", "D", "C", "O", "dx", "invariant_id", "use_window", "precision")] + \
                [("h_true", ctypes.c_int32), ("d_true", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
+class EnfSgdSegment(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("g", ctypes.c_void_p), ("lr", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("n", ctypes.c_int64), ("width", ctypes.c_int32), ("g_stride", ctypes.c_int32), ("lr_len", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+ENF_SGD_MAX_SEGMENTS = 4
 
 
 class EnfError(RuntimeError):
@@ -70,6 +79,7 @@ def load():
     lib.enf_lt_layout.argtypes = [dp, ip, ip, ip, ip, ip, ip]
     lib.enf_pack_pair.argtypes = [dp, ctypes.POINTER(vp), vp, vp]
     lib.enf_mse_value_grad.argtypes = [vp, vp, sz, ctypes.c_float, vp, vp, vp]
+    lib.enf_meta_sgd_update.argtypes = [ctypes.c_int, ctypes.POINTER(EnfSgdSegment), ctypes.c_float, vp]
     lib.enf_ode_conv_forward.argtypes = [ci, ci, ci, ci, vp, vp, i64, i64, vp, vp, vp, vp]
     lib.enf_ode_conv_backward_basis.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp]
     lib.enf_ode_poly_num_features.argtypes = [ci, ci]

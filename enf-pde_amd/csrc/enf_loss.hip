@@ -3,6 +3,9 @@
 //   dout = 2 (out - target) / n * grad_scale
 // so that a fit step is forward -> this kernel -> backward, without a framework autograd graph of tiny
 // elementwise kernels in between.  `loss` is accumulated with one atomic per block: the caller zeroes it.
+//
+// enf_meta_sgd_update: the meta-SGD update of every latent component in ONE launch (pde_trainer.py:206-219):
+//   out_k = x_k - lr_k (scale g_k),   scale = the batch size (the gradient of a batch-mean loss, :206)
 #include <hip/hip_runtime.h>
 #include "enf_layout.h"
 
@@ -28,5 +31,41 @@ extern "C" int enf_mse_value_grad(const float* out, const float* target, size_t 
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(enf_mse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, target, n, 1.0f / (float)n,
                      grad_scale, dout, loss);
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+}
+
+struct SgdArgs { EnfSgdSegment seg[ENF_SGD_MAX_SEGMENTS]; int nseg; float scale; };
+
+__global__ __launch_bounds__(256) void enf_meta_sgd_kernel(SgdArgs A) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < ENF_SGD_MAX_SEGMENTS; ++k) {
+    if (k >= A.nseg) return;
+    const EnfSgdSegment& S = A.seg[k];
+    if (i < S.n) {
+      const int64_t row = i / S.width;
+      const int c = (int)(i - row * S.width);
+      const float g = S.g[row * S.g_stride + c] * A.scale;          // :206
+      S.out[i] = S.x[i] - S.lr[S.lr_len == 1 ? 0 : c] * g;         // :215-219
+      return;
+    }
+    i -= S.n;
+  }
+}
+
+extern "C" int enf_meta_sgd_update(int nseg, const EnfSgdSegment* segs, float scale, void* stream) {
+  if (nseg < 1 || nseg > ENF_SGD_MAX_SEGMENTS || !segs) return ENF_EINVAL;
+  SgdArgs A{};
+  int64_t total = 0;
+  for (int k = 0; k < nseg; ++k) {
+    const EnfSgdSegment& S = segs[k];
+    if (!S.x || !S.g || !S.lr || !S.out || S.n <= 0 || S.width <= 0 || S.g_stride < S.width || S.n % S.width != 0) return ENF_EINVAL;
+    if (S.lr_len != 1 && S.lr_len != S.width) return ENF_EDIM;
+    A.seg[k] = S;
+    total += S.n;
+  }
+  A.nseg = nseg;
+  A.scale = scale;
+  hipLaunchKernelGGL(enf_meta_sgd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }

@@ -395,10 +395,11 @@ class EquivariantCrossAttentionNeF:
         return cm()
 
     @torch.no_grad()
-    def mse_value_and_latent_grads(self, params, x, p, a, gaussian_window_size, target, grad_scale=1.0):
+    def mse_value_and_latent_grads(self, params, x, p, a, gaussian_window_size, target, grad_scale=1.0, loss_out=None):
         """loss = mean((nef.apply(params, x, p, a, window) - target)^2) and grad_scale * d loss / d(p, a, window) in one
         sequence of HIP launches (forward, loss + d out, backward), without building an autograd graph: what one
         inner step of the MAML loop computes (pde_trainer.py:175-207; grad_scale = B there).
+        ``loss_out``: an already ZEROED float32 (1,) tensor to accumulate the loss into (saves the fill per call).
         Returns (loss (1,), dp, da, dwindow or None)."""
         lib = _lib.load()
         sigma = gaussian_window_size if self.use_gaussian_window else None
@@ -410,6 +411,8 @@ class EquivariantCrossAttentionNeF:
                 loss = ((out - target) ** 2).mean()
                 g = torch.autograd.grad(loss * grad_scale, leaves, allow_unused=True)
             g = [torch.zeros_like(t) if gi is None else gi for t, gi in zip(leaves, g)]
+            if loss_out is not None:
+                loss_out.add_(loss.detach().reshape(1))
             return loss.detach().reshape(1), g[0], g[1], (g[2] if sigma is not None else None)
         packed = self.pack(params)
         x, p_, a_ = x.float(), p.float().contiguous(), a.float().contiguous()
@@ -428,7 +431,7 @@ class EquivariantCrossAttentionNeF:
         tgt = target.float().contiguous()
         if tgt.shape != out.shape:
             raise AssertionError(f"target has shape {tuple(tgt.shape)}, expected {tuple(out.shape)}")
-        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        loss = loss_out if loss_out is not None else torch.zeros(1, device=dev, dtype=torch.float32)
         dout = torch.empty_like(out)
         _lib.check(lib.enf_mse_value_grad(_ptr(out), _ptr(tgt), out.numel(), float(grad_scale), _ptr(dout), _ptr(loss), st))
         dp, da = torch.empty_like(p_), torch.empty_like(a_)

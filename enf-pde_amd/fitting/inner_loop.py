@@ -1,5 +1,9 @@
 """MAML inner loop and decode on the HIP path (trainers/pde_trainer.py:122-235, 389-405)."""
+import ctypes
+
 import torch
+
+from .. import _lib
 
 
 def default_meta_sgd_lrs(latent_dim, lr_p=1.0, lr_a=5.0, lr_window=0.0, with_ori=False, device="cuda"):
@@ -20,6 +24,31 @@ def make_masks(num_coords, num_sampled, num_inner_steps, generator=None, device=
 
 def _pose(lat, num_ori_dims):
     return torch.cat((lat["p_pos"], lat["p_ori"]), dim=-1) if num_ori_dims > 0 else lat["p_pos"]
+
+
+def meta_sgd_update(lat, grads, lrs, scale):
+    """One meta-SGD update of every latent component in a single HIP launch (pde_trainer.py:206-219):
+    ``lat[k] - lrs[k] * (scale * grads[k])`` for the keys of ``grads``; the other entries of ``lat`` are passed through.
+    A gradient may be a column slice of a wider (..., P) array (the pose gradient split into p_pos / p_ori)."""
+    lib = _lib.load()
+    new = dict(lat)
+    segs = (_lib.EnfSgdSegment * _lib.ENF_SGD_MAX_SEGMENTS)()
+    keep = []
+    for i, (k, g) in enumerate(grads.items()):
+        x = lat[k].float().contiguous()
+        w = x.shape[-1]
+        if g.dtype != torch.float32 or g.shape != x.shape or g.stride(-1) != 1 or \
+                any(g.stride(d) != g.stride(d + 1) * g.shape[d + 1] for d in range(g.dim() - 2)):
+            g = g.float().contiguous()
+        lr = lrs[k].detach().float().contiguous()
+        out = torch.empty_like(x)
+        keep += [x, g, lr]
+        segs[i] = _lib.EnfSgdSegment(x.data_ptr(), g.data_ptr(), lr.data_ptr(), out.data_ptr(), x.numel(), w,
+                                     g.stride(-2) if g.dim() > 1 else w, lr.numel(), 0)
+        new[k] = out
+    st = ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
+    _lib.check(lib.enf_meta_sgd_update(len(grads), segs, float(scale), st))
+    return new
 
 
 def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaussian_window=False,
@@ -44,27 +73,30 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
 
     # coordinates and targets of all S+1 steps gathered once                 (pde_trainer.py:193-197)
     xs_all = coords[masks.t()]                                           # (S+1, N_s, dx)
-    ys_all = img[:, masks.t()].transpose(0, 1).contiguous()              # (S+1, B, N_s, O)
+    ys_all = img[:, masks.t()].transpose(0, 1).float().contiguous()      # (S+1, B, N_s, O)
+    losses = torch.zeros(S + 1, device=img.device, dtype=torch.float32)  # one accumulator per step, zeroed in one fill
     n_pos = lat["p_pos"].shape[-1]
-    # update coefficients -lr * B (pde_trainer.py:207,215-219); sigma only moves when asked to (pde_trainer.py:210-212)
-    coef = {k: lrs[k] * float(-B) for k in lat}
     for s in range(S):                                                  # pde_trainer.py:191
         xs = xs_all[s][None].expand(B, -1, -1)                          # stride-0 batch
         _, dp, da, dsig = nef.mse_value_and_latent_grads(nef_params, xs, _pose(lat, n_ori), lat["a"],
-                                                         lat.get("gaussian_window"), ys_all[s])
-        new = dict(lat)
-        new["p_pos"] = torch.addcmul(lat["p_pos"], dp[..., :n_pos], coef["p_pos"])
+                                                         lat.get("gaussian_window"), ys_all[s], loss_out=losses[s:s + 1])
+        # the gradient of the batch-mean loss times B (pde_trainer.py:206), scaled by the learned rates (:215-219);
+        # sigma only moves when asked to (:209-212)
+        grads = {"p_pos": dp[..., :n_pos], "a": da}
         if n_ori > 0:
-            new["p_ori"] = torch.addcmul(lat["p_ori"], dp[..., n_pos:], coef["p_ori"])
-        new["a"] = torch.addcmul(lat["a"], da, coef["a"])
+            grads["p_ori"] = dp[..., n_pos:]
         if optimize_gaussian_window and dsig is not None:
-            new["gaussian_window"] = torch.addcmul(lat["gaussian_window"], dsig, coef["gaussian_window"])
-        lat = new
+            grads["gaussian_window"] = dsig
+        lat = meta_sgd_update(lat, grads, lrs, B)
     with torch.no_grad():                                               # pde_trainer.py:225-235
         xs = xs_all[S][None].expand(B, -1, -1)
-        out = nef.apply(nef_params, xs, _pose(lat, n_ori), lat["a"], lat.get("gaussian_window"))
-        loss = ((out - ys_all[S]) ** 2).mean()
-    return loss, lat
+        out = nef.apply(nef_params, xs, _pose(lat, n_ori), lat["a"], lat.get("gaussian_window")).float().contiguous()
+        st = ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
+        if out.shape != ys_all[S].shape:
+            raise AssertionError(f"targets have shape {tuple(ys_all[S].shape)}, expected {tuple(out.shape)}")
+        _lib.check(_lib.load().enf_mse_value_grad(out.data_ptr(), ys_all[S].data_ptr(), out.numel(), 1.0, None,
+                                                  losses[S:].data_ptr(), st))
+    return losses[S], lat
 
 
 @torch.no_grad()

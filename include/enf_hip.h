@@ -234,6 +234,22 @@ int enf_set_relu_masks(void* masks, int mode, int mask_signals);
 int enf_mse_value_grad(const float* out, const float* target, size_t n, float grad_scale, float* dout, float* loss,
                        void* stream);
 
+/* The meta-SGD update of one inner step for all latent components in one launch (pde_trainer.py:206-219):
+ *     out = x - lr * (scale * g)        scale = the batch size (:206); lr broadcasts over the leading dims
+ * A segment is one component (p_pos, p_ori, a, gaussian_window): x, out contiguous (n elements, trailing dimension
+ * `width`); g may be a column slice of a wider array: element (row, c) is g[row * g_stride + c]; lr holds 1 or `width`
+ * values (trainers/pde_trainer.py:83-97).  A component whose update is zeroed (:209-212) is simply left out. */
+#define ENF_SGD_MAX_SEGMENTS 4
+typedef struct EnfSgdSegment {
+  const float* x;
+  const float* g;
+  const float* lr;
+  float* out;
+  int64_t n;
+  int32_t width, g_stride, lr_len, reserved;
+} EnfSgdSegment;
+int enf_meta_sgd_update(int nseg, const EnfSgdSegment* segs, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Latent ODE (experiments/fitting/ode_models/ponita_ode_g.py): the separable group convolution of a ConvBlock,
  * SepGconv.__call__ (:63-83), over the fully connected latent set of every signal:
