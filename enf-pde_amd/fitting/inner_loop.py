@@ -72,8 +72,9 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
                                                   device="cpu").to(lat["p_pos"].device) * noise_pos
 
     # coordinates and targets of all S+1 steps gathered once                 (pde_trainer.py:193-197)
-    xs_all = coords[masks.t()]                                           # (S+1, N_s, dx)
-    ys_all = img[:, masks.t()].transpose(0, 1).float().contiguous()      # (S+1, B, N_s, O)
+    masks_t = masks.t().contiguous()                                     # (a gather inherits the strides of a transposed index)
+    xs_all = coords[masks_t]                                             # (S+1, N_s, dx)
+    ys_all = img[:, masks_t].transpose(0, 1).float().contiguous()        # (S+1, B, N_s, O)
     losses = torch.zeros(S + 1, device=img.device, dtype=torch.float32)  # one accumulator per step, zeroed in one fill
     n_pos = lat["p_pos"].shape[-1]
     for s in range(S):                                                  # pde_trainer.py:191
