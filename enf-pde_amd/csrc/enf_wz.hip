@@ -197,8 +197,12 @@ static int launch_wz(const WzArgs& A, hipStream_t st) {
   }
   // waves = COMBOS (head, block) roles x a number of latent lanes; each wave sweeps BZ / lanes latents
   constexpr int COMBOS = H * (D / 32);
-  static int maxgrid = 0;
-  if (!maxgrid) { const char* e = getenv("ENF_WZ_GRID"); maxgrid = e ? atoi(e) : ENF_WZ_MAXGRID; if (maxgrid < 2) maxgrid = 2; }
+  // the backward's call (both orientations) runs on the side stream beside the tail kernels and is off the critical
+  // path with half the chip (same-box A/B of the fit: 3.036 ms with 128 workgroups, 3.052 with 256); the decode's call
+  // is ON the critical path and takes the whole chip
+  static int envgrid = -1;
+  if (envgrid < 0) { const char* e = getenv("ENF_WZ_GRID"); envgrid = e ? atoi(e) : 0; if (envgrid == 1) envgrid = 2; }
+  const int maxgrid = envgrid > 0 ? envgrid : (A.wzt ? ENF_WZ_MAXGRID / 2 : ENF_WZ_MAXGRID);
   const int max_waves = maxgrid * WZ_WAVES;
   int lanes = A.BZ;
   while (lanes * COMBOS > max_waves && lanes > 1) lanes = (lanes + 1) / 2;

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Same-box A/B of bench.py over values of one environment variable: scripts/ab_env.sh VAR v1 v2 ...   (3 rounds)
+VAR=$1; shift
+for r in 1 2 3; do
+  for v in "$@"; do
+    env $VAR=$v timeout -k 10 120 python bench.py --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$VAR=$v', d['ms_per_step'], 'fit', d['split']['ms_fit'], 'decode', d['split']['ms_decode'])"
+  done
+done
