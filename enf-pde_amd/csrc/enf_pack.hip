@@ -310,6 +310,10 @@ extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* p
 #define ENF_PROLOGUE_ZT 4
 #endif
 constexpr int ZT = ENF_PROLOGUE_ZT;   // latents per block (multiple of 4)
+#ifndef ENF_PROLOGUE_UNROLL
+#define ENF_PROLOGUE_UNROLL 16         // independent weight loads in flight per thread: these kernels are latency chains
+#endif
+#define PRO_UNROLL ENF_PROLOGUE_UNROLL
 typedef float pf4 __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ float wave_sum(float v) {
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
     const float bs = W(A.L.stem_b)[d];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = bs;
-#pragma unroll 4
+#pragma unroll PRO_UNROLL
     for (int c = 0; c < C; ++c) {
       const float w = W(A.L.stem_w)[(size_t)c * D + d];
 #pragma unroll
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
     const float bb = W(isv ? A.L.bv : A.L.bk)[jj];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = bb;
-#pragma unroll 8
+#pragma unroll PRO_UNROLL
     for (int d = 0; d < D; ++d) {
       const float w = Wm[(size_t)d * HD + jj];
 #pragma unroll
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
     float acc[ZT];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = 0.f;
-#pragma unroll 8
+#pragma unroll PRO_UNROLL
     for (int dd = 0; dd < D; ++dd) {
       const float w = mut[(size_t)dd * D];
       const float* kp = s_k + (h * D + dd) * ZT;
@@ -508,6 +512,7 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
   float* s_dk = s_du + ZT * HD;        // [2HD][ZT] d k | d v0
   float* s_dan = s_dk + ZT * 2 * HD;   // [D][ZT]
   float* s_dc = s_dan + ZT * D;        // [H][ZT]
+  float* s_part = s_dc + ZT * H;       // [256][ZT] partial sums of the d(an) stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * ZT;
   const int stride = enf_lt_stride(H, D);
   auto W = [&](size_t off) { return reinterpret_cast<const float*>(A.blob + off); };
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
     float acc[ZT];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = cv * s_dc[h * ZT + zz];
-#pragma unroll 8
+#pragma unroll PRO_UNROLL
     for (int i = 0; i < D; ++i) {
       const float w = mu[(size_t)i * D];
       const float* gp = s_du + (h * D + i) * ZT;
@@ -545,15 +550,17 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
     for (int zz = 0; zz < ZT; ++zz) s_dk[j * ZT + zz] = acc[zz];
   }
   __syncthreads();
-  // d(an_affine)[d] = sum_j Wk[d][j] dk[j] + Wv[d][j] dv0[j]  (wkT/wvT: [j][d]); then through scale: dxn = dy * g
-  for (int d = tid; d < D; d += 256) {
+  // d(an_affine)[d] = sum_j Wk[d][j] dk[j] + Wv[d][j] dv0[j]  (wkT/wvT: [j][d]); then through scale: dxn = dy * g.
+  // D outputs only: the 256 / D thread groups each take a slice of j and the partial sums meet in LDS
+  {
+    const int nsplit = 256 / D, d = tid % D, part = tid / D, jper = HD / nsplit;
     float acc[ZT];
 #pragma unroll
     for (int zz = 0; zz < ZT; ++zz) acc[zz] = 0.f;
     const float* wkt = W(A.L.wkt) + d;
     const float* wvt = W(A.L.wvt) + d;
-#pragma unroll 4
-    for (int j = 0; j < HD; ++j) {
+#pragma unroll PRO_UNROLL
+    for (int j = part * jper; j < (part + 1) * jper; ++j) {
       const float wk = wkt[(size_t)j * D], wv = wvt[(size_t)j * D];
 #pragma unroll
       for (int q = 0; q < ZT / 4; ++q) {
@@ -562,9 +569,18 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
         for (int zz = 0; zz < 4; ++zz) acc[4 * q + zz] = fmaf(wk, kq[zz], fmaf(wv, vq[zz], acc[4 * q + zz]));
       }
     }
-    const float g = W(A.L.lna_g)[d];
 #pragma unroll
-    for (int zz = 0; zz < ZT; ++zz) s_dan[d * ZT + zz] = acc[zz] * g;
+    for (int zz = 0; zz < ZT; ++zz) s_part[tid * ZT + zz] = acc[zz];
+    __syncthreads();
+    if (tid < D) {
+      const float g = W(A.L.lna_g)[tid];
+#pragma unroll
+      for (int zz = 0; zz < ZT; ++zz) {
+        float v = 0.f;
+        for (int q = 0; q < nsplit; ++q) v += s_part[(q * D + tid) * ZT + zz];
+        s_dan[tid * ZT + zz] = v * g;
+      }
+    }
   }
   __syncthreads();
   // LayerNorm backward: ds = rstd * (dxn - mean(dxn) - xn * mean(dxn * xn)); one wave per row
@@ -583,6 +599,7 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
   for (int t = tid; t < ZT * C; t += 256) {
     const int zz = t / C, c = t % C, r = row0 + zz;
     float sacc = 0.f;
+#pragma unroll PRO_UNROLL
     for (int d = 0; d < D; ++d) sacc = fmaf(W(A.L.stem_w)[(size_t)c * D + d], s_dan[d * ZT + zz], sacc);
     if (r < A.BZ) A.da[(size_t)r * C + c] = sacc;
   }
@@ -624,7 +641,7 @@ extern "C" int enf_launch_prologue_bwd(const EnfDims& m, const EnfLayout& L, con
   A.p = p; A.sigma = sigma; A.blob = blob; A.L = L; A.an = an; A.kv = kv; A.dlt = dlt;
   A.dp = dp; A.da = da; A.dsigma = dsigma;
   A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp_dim = m.dp; A.inv = m.inv; A.Dt = m.Dt;
-  const size_t smem = sizeof(float) * (ZT * 3 * m.HD + ZT * m.D + ZT * m.H);
+  const size_t smem = sizeof(float) * (ZT * 3 * m.HD + ZT * m.D + ZT * m.H + ZT * 256);
   hipLaunchKernelGGL(enf_prologue_bwd_kernel, dim3((A.BZ + ZT - 1) / ZT), dim3(256), smem, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
