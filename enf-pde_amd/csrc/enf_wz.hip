@@ -76,6 +76,19 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
       for (int kt = 0; kt < NT; ++kt)
         bb[a][kt] = *reinterpret_cast<const f32x4*>(wbm + (size_t)(16 * (2 * blk + a) + col) * D + 16 * kt + 4 * quad);
   }
+  // bias row c_zh: every wave takes NT / KB of its k-tiles (one wave doing all of them was the slowest of its group);
+  // its latent-independent operands are resident too
+  constexpr int BT = NT / KB;
+  f32x4 gq[NT];
+  float cbv[BT];
+  {
+    const float* opbg = G(A.L.p_opbg) + h * D;
+    const float* cb = G(A.L.p_cb) + h * D;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) gq[tj] = *reinterpret_cast<const f32x4*>(opbg + 16 * tj + 4 * quad);
+#pragma unroll
+    for (int t = 0; t < BT; ++t) cbv[t] = cb[16 * (BT * blk + t) + col];
+  }
   for (int bz = gw / COMBOS; bz < A.BZ; bz += lat_stride) {
     const float* v0 = A.lt + (size_t)bz * ltstride + enf_lt_off_v0(H, D) + h * D;
     // "activation" fragments: X[i][j] = Wgamma_h[i][j] v0[j], rows i = 16 (2 blk + a) + col as columns
@@ -90,6 +103,20 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) X[tj] = wg[a][tj] * v[tj];
         make_frags<BF16, KB>(FX[a], X);
+      }
+      // bias row: column 0 carries v0 (1 + bgamma_h); the product's row 0 is c_zh - cb_h
+      f32x4 X[NT];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) X[tj] = col == 0 ? v[tj] * gq[tj] : f32x4{0.f, 0.f, 0.f, 0.f};
+      Frags<BF16, KB> FB;
+      make_frags<BF16, KB>(FB, X);
+      float* dst = A.wzb + (size_t)(bz * H + h) * D;
+#pragma unroll
+      for (int t = 0; t < BT; ++t) {
+        const int kt = BT * blk + t;
+        f32x4 ab = {0.f, 0.f, 0.f, 0.f};
+        gemm_tile_flip<BF16, KB>(ab, FB, smem, kt, lane);
+        if (quad == 0) dst[16 * kt + col] = ab[0] + cbv[t];
       }
     }
     char* panel = A.wz + (size_t)(bz * H + h) * A.pstride;
@@ -160,26 +187,6 @@ __global__ __launch_bounds__(64 * WZ_WAVES) void enf_wz_kernel(WzArgs A) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
         *reinterpret_cast<bf16x8*>(A.wzu + (size_t)bz * enf_wzu_bytes(H, D) + lane * 16) = o;
-      }
-    }
-    if (blk == 0) {      // bias row: column 0 carries v0 (1 + bgamma_h); the product's row 0 is c_zh - cb_h
-      const float* opbg = G(A.L.p_opbg) + h * D;
-      const float* cb = G(A.L.p_cb) + h * D;
-      f32x4 X[NT];
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(v0 + 16 * tj + 4 * quad);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(opbg + 16 * tj + 4 * quad);
-        X[tj] = col == 0 ? v * g : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      Frags<BF16, KB> FB;
-      make_frags<BF16, KB>(FB, X);
-      float* dst = A.wzb + (size_t)(bz * H + h) * D;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        f32x4 ab = {0.f, 0.f, 0.f, 0.f};
-        gemm_tile_flip<BF16, KB>(ab, FB, smem, kt, lane);
-        if (quad == 0) dst[16 * kt + col] = ab[0] + cb[16 * kt + col];
       }
     }
   }
