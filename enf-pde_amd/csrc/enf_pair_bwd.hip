@@ -311,6 +311,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   float* zv = reinterpret_cast<float*>(smem + SM::ZVEC) + wave * 2 * H * D;
   const char* blob = A.blob;
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
+  // The waves of a workgroup start aligned.  Without this barrier the unfolded 64-wide bf16 instantiation with two heads
+  // gave gradients that changed from run to run by ~1e-2 (scripts/diag_k3_unfolded.py, scripts/diag_determinism.py: 6 of 6
+  // processes; 0 of 8 with it, whether or not any LDS was cleared first) -- a start-up race whose other party is NOT yet
+  // identified (open issues); the barrier costs nothing measurable on a 0.5 ms kernel.
+  __syncthreads();
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
   const int bz = ZF ? (int)blockIdx.x : blockIdx.x * NW + wave;
