@@ -169,3 +169,34 @@ def test_weight_grads_random_shape_sweep(cuda, case):
     B, N, Z = int(rng.integers(1, 4)), int(rng.integers(2, 120)), int(rng.integers(2, 30))
     cfg = make_cfg(inv, D=D, H=H, C=int(rng.integers(2, 20)), O=int(rng.integers(1, 4)), freq=(0.3, 0.6))
     check(cuda, cfg, B=B, N=N, Z=Z, precision="f32" if case % 2 == 0 else "bf16", seed=4000 + case)
+
+
+def test_weight_grads_are_reproducible(cuda):
+    """The training path's kernel (unfolded chain with the activation store) at D = 64, H = 2, bf16: the same inputs give the
+    same weight and latent gradients run after run (see tests/test_gpu_backward.py::test_backward_is_reproducible)."""
+    cfg = make_cfg("rel_pos", D=64, H=2, C=7, O=2, freq=(0.3, 0.6))
+    prm = R.init_params(5, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 2, 87, 11, 6)
+    w = np.random.default_rng(7).standard_normal((2, 87, cfg["num_out"]))
+    first = None
+    for it in range(8):
+        junk = [torch.randn(int(n), device=cuda) * 10 for n in np.random.default_rng(it).integers(1 << 10, 1 << 21, 8)]
+        del junk
+        res = hip(cuda, build_nef(cfg, "bf16"), prm, x, p, a, s, w)
+        flat = np.concatenate([np.asarray(v, dtype=np.float64).ravel() for v in _leaves_of(res)])
+        if first is None:
+            first = flat
+            continue
+        d = np.linalg.norm(flat - first) / np.linalg.norm(first)
+        assert d < 1e-5, (it, d)
+
+
+def _leaves_of(obj):
+    if isinstance(obj, dict):
+        for k in sorted(obj):
+            yield from _leaves_of(obj[k])
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _leaves_of(v)
+    else:
+        yield obj.detach().cpu().numpy() if hasattr(obj, "detach") else obj
