@@ -315,7 +315,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // gave gradients that changed from run to run by ~1e-2 (scripts/diag_k3_unfolded.py, scripts/diag_determinism.py: 6 of 6
   // processes; 0 of 8 with it, whether or not any LDS was cleared first) -- a start-up race whose other party is NOT yet
   // identified (open issues); the barrier costs nothing measurable on a 0.5 ms kernel.
+#ifndef ENF_DIAG_BARRIER_POS
   __syncthreads();
+#endif
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
   const int bz = ZF ? (int)blockIdx.x : blockIdx.x * NW + wave;
@@ -374,6 +376,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   else P.rs2 = P.rs;
   const unsigned pWG = (unsigned)A.L.awg;
   first_stage<ST_DD>(P, ring, pQ1, wave, lane);
+#if defined(ENF_DIAG_BARRIER_POS) && ENF_DIAG_BARRIER_POS == 2
+  __syncthreads();
+#endif
+#if defined(ENF_DIAG_BARRIER_POS) && ENF_DIAG_BARRIER_POS == 3
+  for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);       // ~8 x 127 x 64 cycles: time, but no synchronisation
+#endif
+#if defined(ENF_DIAG_BARRIER_POS) && ENF_DIAG_BARRIER_POS == 4
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's own outstanding accesses only
+#endif
 
   // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature
   // 16 t + col, summed over the queries n = 4 quad + i of every tile (flipped products).
