@@ -6,6 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ENF_HIP_LIB") or os.path.join(_HERE, "libenf_hip.so")   # ENF_HIP_LIB: A/B builds (scripts/build_variant.sh)
+TEST_LIB_PATH = os.path.join(_HERE, "libenf_hip_test.so")    # same ABI + test hooks (csrc/Makefile); loaded by tests only
 
 ENF_NUM_TENSORS = 46
 PREC = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
@@ -47,6 +48,7 @@ class EnfError(RuntimeError):
 
 
 _lib = None
+_test_lib = None
 
 
 def load():
@@ -54,10 +56,39 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise EnfError(f"{LIB_PATH} not found: build it with `make -C enf-pde_amd/csrc` "
+    _lib = _bind(LIB_PATH, test_hooks=False)
+    return _lib
+
+
+def load_test():
+    """The test library (libenf_hip_test.so): the whole product ABI plus the test-only entry points.  Tests only."""
+    global _test_lib
+    if _test_lib is None:
+        _test_lib = _bind(TEST_LIB_PATH, test_hooks=True)
+    return _test_lib
+
+
+class using:
+    """Context manager for tests: route the package's calls through another build of the library (e.g. load_test())."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        global _lib
+        self.prev, _lib = _lib, self.lib
+        return self.lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+
+
+def _bind(path, test_hooks):
+    if not os.path.exists(path):
+        raise EnfError(f"{path} not found: build it with `make -C enf-pde_amd/csrc` "
                        "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, i64, sz, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t, ctypes.c_int
     dp = ctypes.POINTER(EnfDesc)
     lib.enf_abi_version.restype = ci
@@ -97,13 +128,14 @@ def load():
     lib.enf_pair_forward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, sz, vp]
     lib.enf_pair_backward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp), vp]
     lib.enf_pair_backward_ex.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp), vp, vp]
-    for name in ("enf_debug_gemm", "enf_debug_pack"):
-        getattr(lib, name).restype = ci
-    lib.enf_debug_gemm.argtypes = [vp, vp, vp, ci, ci, ci, vp]
-    lib.enf_debug_pack.argtypes = [vp, vp, ci, ci, ci, vp]
+    if test_hooks:
+        for name in ("enf_debug_gemm", "enf_debug_pack", "enf_test_read_wave_sums"):
+            getattr(lib, name).restype = ci
+        lib.enf_debug_gemm.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+        lib.enf_debug_pack.argtypes = [vp, vp, ci, ci, ci, vp]
+        lib.enf_test_read_wave_sums.argtypes = [vp]
     if lib.enf_abi_version() != 1:
-        raise EnfError("libenf_hip.so ABI version mismatch")
-    _lib = lib
+        raise EnfError(f"{path}: ABI version mismatch")
     return lib
 
 

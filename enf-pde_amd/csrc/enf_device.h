@@ -59,9 +59,6 @@ DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
 #ifndef ENF_GELU_POLY
 #define ENF_GELU_POLY 0
 #endif
-#ifndef ENF_RELU_ASM
-#define ENF_RELU_ASM 1
-#endif
 #include "enf_gemm_asm.h"
 #ifndef ENF_ASM_GEMM
 #define ENF_ASM_GEMM 1
@@ -83,23 +80,31 @@ template <bool BF16, int NT> struct Parked {
   }
 };
 
-// relu on fragments.  bf16: as 16-bit integers negative floats are negative, so one v_pk_max_i16 with 0
-// clamps two values (-0 -> +0); fp32: v_max per value.
+// relu of one fp32 value as ONE integer max (negative floats, -0 included, are negative integers; positive floats pass
+// through), without the canonicalising second v_max that fmaxf(x, 0) costs.
+// NOT inline asm: an asm VALU instruction is invisible to hipcc's hazard recognizer, so when its input is the result of a
+// compiler-scheduled MFMA no wait states are inserted and it reads a stale accumulator (gfx950 needs 7 between a
+// v_mfma_f32_16x16x32_bf16 and a VALU read of its result and does not interlock: scripts/ubench/mfma_hazard.hip).  Round 1 had
+// `asm("v_max_f32 %0, 0, %1")` here: harmless behind the hand-written GEMM stages (they end in s_nop 11), wrong behind the
+// compiler-scheduled ones (fp32 mode; -DENF_ASM_GEMM=0) -- DESIGN.md, "K3 run-to-run deviations".
+DEV float relu_f(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
+
+// relu on fragments.  bf16: as 16-bit integers negative floats are negative, so one v_pk_max_i16 with 0 clamps two values
+// (-0 -> +0); fp32: relu_f per value.  Compiler-visible operations for the same reason as relu_f.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <bool BF16, int KB> DEV void relu_frags(Frags<BF16, KB>& F) {
   if constexpr (BF16) {
 #pragma unroll
     for (int blk = 0; blk < KB; ++blk) {
-      u32x4 w = __builtin_bit_cast(u32x4, F.f[blk]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm("v_pk_max_i16 %0, %1, 0" : "=v"(w[i]) : "v"(w[i]));
-      F.f[blk] = __builtin_bit_cast(bf16x8, w);
+      const s16x8 w = __builtin_bit_cast(s16x8, F.f[blk]);
+      F.f[blk] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(w, (s16x8)0));
     }
   } else {
 #pragma unroll
     for (int t = 0; t < 2 * KB; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) F.f[t][i] = fmaxf(F.f[t][i], 0.f);
+      for (int i = 0; i < 4; ++i) F.f[t][i] = relu_f(F.f[t][i]);
   }
 }
 
@@ -289,16 +294,6 @@ template <int NT> DEV void gelu_fg_tiles(f32x4 (&X)[NT], f32x4 (&G)[NT]) {
     X[t] = f32x4{g0[0], g0[1], g1[0], g1[1]};
     G[t] = f32x4{d0[0], d0[1], d1[0], d1[1]};
   }
-}
-// relu without the canonicalising second v_max that fmaxf(x, 0) costs (MFMA results are never signalling)
-DEV float relu_f(float x) {
-#if ENF_RELU_ASM
-  float y;
-  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-  return y;
-#else
-  return fmaxf(x, 0.f);
-#endif
 }
 // d/dx of the above: s + x s (1-s) 2c(1+3*0.044715x^2),  s = sigmoid(2c(x+0.044715x^3))
 DEV float gelu_grad_f(float x) {

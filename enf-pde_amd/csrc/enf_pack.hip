@@ -220,13 +220,15 @@ extern "C" int enf_pack_pair(const EnfDesc* d, const float* const* T, void* pack
                           T[ENF_P_COEFV]);
 }
 
-// test-only: pack a plain fp32 (K x M row-major, W[k][m]) matrix as the A operand A[m][k] = W[k][m]
+#ifdef ENF_TEST_HOOKS
+// test-only build (libenf_hip_test.so): pack a plain fp32 (K x M row-major, W[k][m]) matrix as the A operand A[m][k] = W[k][m]
 extern "C" int enf_debug_pack(void* dst, const float* W, int M, int K, int bf16, void* stream) {
   const size_t total = (size_t)M * K;
   hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, W, M,
                      M, K, 0, bf16, M, K, 1.0f);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
+#endif
 
 extern "C" int enf_pack_weights(const EnfDesc* d, const float* const* T, void* packed, void* stream) {
   if (!d || !T || !packed) return ENF_EINVAL;

@@ -82,6 +82,17 @@ extern "C" int enf_debug_read_stamps_bwd(unsigned long long* dst) {
 #define BSTAMP(k) do {} while (0)
 #endif
 
+#ifdef ENF_TEST_HOOKS
+// Test-only build (libenf_hip_test.so, `make test-lib`): the kernel's EPILOGUE also writes every wave's final per-latent sums,
+// so a test can compare the waves that recompute the same latent (the inactive waves of the last workgroup keep the barrier
+// cadence on the last latent) bit for bit inside ONE launch.  The tile loop is untouched; the product library has none of this.
+constexpr int ENF_HOOK_WGS = 64, ENF_HOOK_ROW = 16 * 64 + 16;
+__device__ float enf_hook_wave_sums[ENF_HOOK_WGS * NWAVES * ENF_HOOK_ROW];
+extern "C" int enf_test_read_wave_sums(float* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(enf_hook_wave_sums), sizeof(enf_hook_wave_sums)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // one row of a materialised activation / delta = this lane's share of a fragment set.
 // bf16: the 8 values of a fragment go out as ONE 16-byte store at columns 32 blk + 8 quad + j, i.e. the row is stored
 // with its columns PERMUTED inside every 32-block (true feature = 32 blk + 4 quad + j for j < 4, 32 blk + 16 + 4 quad +
@@ -311,13 +322,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   float* zv = reinterpret_cast<float*>(smem + SM::ZVEC) + wave * 2 * H * D;
   const char* blob = A.blob;
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
-  // The waves of a workgroup start aligned.  Without this barrier the unfolded 64-wide bf16 instantiation with two heads
-  // gave gradients that changed from run to run by ~1e-2 (scripts/diag_k3_unfolded.py, scripts/diag_determinism.py: 6 of 6
-  // processes; 0 of 8 with it, whether or not any LDS was cleared first) -- a start-up race whose other party is NOT yet
-  // identified (open issues); the barrier costs nothing measurable on a 0.5 ms kernel.
-#ifndef ENF_DIAG_BARRIER_POS
+  // Entry barrier: no wave touches LDS or issues a load before all eight waves of the workgroup are resident (the first four
+  // are launched up to ~1000 cycles ahead of the last two, scripts/k3_race/README.md).  Without it the unfolded 64-wide bf16
+  // two-head instantiation returned run-to-run different gradients for the latents of waves 4-7 (the first-launched, older
+  // wave of each SIMD).  Round 2 established what this is NOT -- not the LDS-DMA ring (read-back, poison and register-staging
+  // builds), not a missed barrier (phase self-check), not a stale scalar cache, not a documented MFMA / trans hazard (all
+  // measured, scripts/ubench/) -- and found and removed one real defect of the same symptom (inline-asm relu behind
+  // compiler-scheduled MFMAs, enf_device.h: relu_f).  The remaining effect was never observed with this barrier (0 of ~5000
+  // duplicate-wave checks, tests/test_gpu_backward.py::test_duplicate_waves_agree) and its mechanism is still open: DESIGN.md.
   __syncthreads();
-#endif
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
   const int bz = ZF ? (int)blockIdx.x : blockIdx.x * NW + wave;
@@ -376,15 +389,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   else P.rs2 = P.rs;
   const unsigned pWG = (unsigned)A.L.awg;
   first_stage<ST_DD>(P, ring, pQ1, wave, lane);
-#if defined(ENF_DIAG_BARRIER_POS) && ENF_DIAG_BARRIER_POS == 2
-  __syncthreads();
-#endif
-#if defined(ENF_DIAG_BARRIER_POS) && ENF_DIAG_BARRIER_POS == 3
-  for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);       // ~8 x 127 x 64 cycles: time, but no synchronisation
-#endif
-#if defined(ENF_DIAG_BARRIER_POS) && ENF_DIAG_BARRIER_POS == 4
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's own outstanding accesses only
-#endif
 
   // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature
   // 16 t + col, summed over the queries n = 4 quad + i of every tile (flipped products).
@@ -908,6 +912,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     } else if (has_ph && quad == 1) { eacc[9 * 16] += dlat[0]; eacc[10 * 16] += dlat[1]; }
   }
 
+#ifdef ENF_TEST_HOOKS
+  if constexpr (ENF_K3_LDSACC != 0 && 2 * H * (D / 16) <= 16) {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < ENF_HOOK_WGS) {
+      float* o = enf_hook_wave_sums + (size_t)(wg * NWAVES + wave) * ENF_HOOK_ROW;
+      for (int k = 0; k < 2 * H * NT; ++k) o[k * 64 + lane] = lacc[k * 64];
+      float q0[H + 5];
+      for (int h = 0; h < H; ++h) q0[h] = dC[h];
+      q0[H] = dpose[0]; q0[H + 1] = dpose[1]; q0[H + 2] = dpose[2]; q0[H + 3] = dpose[3]; q0[H + 4] = dwc;
+      for (int i = 0; i < H + 5; ++i) {
+        float a = quad == 0 ? q0[i] : 0.f;
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) o[16 * 64 + i] = a;
+      }
+      if (lane == 0) { o[16 * 64 + 8] = (float)bz; o[16 * 64 + 9] = (float)bzc; o[16 * 64 + 10] = (float)my_tiles; }
+    }
+  }
+#endif
   // ---- fold the partial sums and add this wave's share into the latent-table gradient
   if (!active) return;   // no barrier follows
   float* drow = A.dlt + (size_t)bz * ltstride;

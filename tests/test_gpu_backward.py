@@ -115,3 +115,40 @@ def test_backward_is_reproducible(cuda, H, bwd_variant):
             continue
         for name, r0, r1 in zip(("out", "dp", "da", "dsigma"), first, res):
             assert rel(r1, r0) < 1e-5, (name, it, rel(r1, r0))
+
+
+@pytest.mark.parametrize("D,H,precision", [(64, 2, "bf16"), (64, 1, "bf16"), (128, 2, "bf16"), (128, 1, "bf16"), (64, 2, "f32")])
+def test_duplicate_waves_agree(cuda, D, H, precision):
+    """In-launch determinism of the unfolded backward pair kernel.  With B*Z = 2 latents the waves 2..7 of every workgroup are
+    inactive and recompute latent 1 to keep the barrier cadence, so inside ONE launch six waves must reproduce wave 1's final
+    per-latent sums bit for bit.  Needs the test library (libenf_hip_test.so: the kernel's epilogue dumps every wave's sums;
+    the tile loop is the product's).  This check caught what the run-to-run comparison above only saw on some GPUs: VALU reads
+    of MFMA results without the wait states gfx950 needs ("K3 run-to-run deviations")."""
+    import ctypes
+    from enf_pde_amd import _lib
+    tl = _lib.load_test()
+    cfg = make_cfg("ponita", D=D, H=H, C=7, O=2, freq=(0.3, 0.6))
+    prm = R.init_params(5, cfg, jitter=0.1)
+    N = 1400
+    x, p, a, s = make_inputs(cfg, 1, N, 2, 6)
+    w = np.random.default_rng(7).standard_normal((1, N, cfg["num_out"]))
+    row = 16 * 64 + 16
+    with _lib.using(tl):
+        tl.enf_set_zfold(0)
+        tl.enf_set_zfold_bwd(0)
+        try:
+            for it in range(4):
+                hip_grads(cuda, build_nef(cfg, precision), prm, x, p, a, s, w)
+                buf = (ctypes.c_float * (64 * 8 * row))()
+                assert tl.enf_test_read_wave_sums(buf) == 0
+                sums = np.array(buf, dtype=np.float32).reshape(64, 8, row)
+                launched = sums[:, 0, 16 * 64 + 10] > 0                       # tiles swept by wave 0 of the workgroup
+                assert launched.sum() >= 32
+                assert (sums[launched][:, 1:, 16 * 64 + 9] == 1).all()         # every wave from 1 on worked on latent 1
+                ref = sums[launched][:, 1:2, :16 * 64 + H + 5]
+                dup = sums[launched][:, 2:, :16 * 64 + H + 5]
+                differ = (dup != ref).any(-1)
+                assert not differ.any(), (it, int(differ.sum()), "duplicate waves differ from wave 1; per wave", differ.sum(0).tolist())
+        finally:
+            tl.enf_set_zfold(-1)
+            tl.enf_set_zfold_bwd(-1)
