@@ -16,9 +16,9 @@ INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic"
 EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
            "enf_backward_latents", "enf_backward_latents_ex", "enf_forward_stages", "enf_lt_layout", "enf_lt_layout_ext", "enf_pack_pair", "enf_pair_forward",
-           "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_set_zfold", "enf_set_zfold_bwd", "enf_mse_value_grad",
+           "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_pair_variant", "enf_mse_value_grad",
            "enf_ode_conv_forward", "enf_ode_conv_backward_basis", "enf_ode_poly_num_features", "enf_ode_poly_forward",
-           "enf_ode_poly_backward", "enf_relu_mask_bytes", "enf_set_relu_masks", "enf_meta_sgd_update"]
+           "enf_ode_poly_backward", "enf_relu_mask_bytes", "enf_meta_sgd_update"]
 ENF_NUM_PAIR_TENSORS = 12          # ENF_P_* of include/enf_hip.h
 (ENF_S_EQ, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0) = range(8)
 
@@ -31,7 +31,14 @@ def num_store(H):
 class EnfDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("B", "N", "Z", "H", "D", "C", "O", "dx", "invariant_id", "use_window", "precision")] + \
-               [("h_true", ctypes.c_int32), ("d_true", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+               [("h_true", ctypes.c_int32), ("d_true", ctypes.c_int32),
+                # per-call options (include/enf_hip.h): the library keeps no settings
+                ("pair_fwd_variant", ctypes.c_int32), ("pair_bwd_variant", ctypes.c_int32), ("mask_mode", ctypes.c_int32),
+                ("mask_signals", ctypes.c_int32), ("reserved", ctypes.c_int32), ("relu_masks", ctypes.c_void_p)]
+
+
+VARIANT = {"auto": 0, "latent_split": 1, "z_fold": 2}       # ENF_VARIANT_*
+MASK_MODE = {"off": 0, "write": 1, "read": 2}                # ENF_MASK_*
 
 
 class EnfSgdSegment(ctypes.Structure):
@@ -118,11 +125,7 @@ def _bind(path, test_hooks):
     lib.enf_ode_poly_backward.argtypes = [i64, ci, ci, vp, vp, vp, vp]
     lib.enf_relu_mask_bytes.restype = sz
     lib.enf_relu_mask_bytes.argtypes = [dp]
-    lib.enf_set_relu_masks.argtypes = [vp, ci, ci]
-    lib.enf_set_zfold.restype = None
-    lib.enf_set_zfold.argtypes = [ci]
-    lib.enf_set_zfold_bwd.restype = None
-    lib.enf_set_zfold_bwd.argtypes = [ci]
+    lib.enf_pair_variant.argtypes = [dp, ci]
     lib.enf_pair_scratch_bytes.restype = sz
     lib.enf_pair_scratch_bytes.argtypes = [dp]
     lib.enf_pair_forward.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, sz, vp]
@@ -134,7 +137,7 @@ def _bind(path, test_hooks):
         lib.enf_debug_gemm.argtypes = [vp, vp, vp, ci, ci, ci, vp]
         lib.enf_debug_pack.argtypes = [vp, vp, ci, ci, ci, vp]
         lib.enf_test_read_wave_sums.argtypes = [vp]
-    if lib.enf_abi_version() != 1:
+    if lib.enf_abi_version() != 2:
         raise EnfError(f"{path}: ABI version mismatch")
     return lib
 
@@ -153,9 +156,27 @@ def check(rc):
     raise EnfError(f"libenf_hip error {rc}: {msg}")
 
 
-def make_desc(B, N, Z, H, D, C, O, dx, invariant_id, use_window, precision, d_true=0, h_true=0):
+def launch(dev, fn, *args):
+    """Call a library entry point that enqueues work on a stream of ``dev`` (a torch.device) with ``dev`` as the calling
+    thread's current device -- the library's per-device bookkeeping (side stream, kernel attributes) goes by it -- and map
+    its return code like ``check``."""
+    import torch
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx == torch.cuda.current_device():
+        return check(fn(*args))
+    with torch.cuda.device(idx):
+        return check(fn(*args))
+
+
+def make_desc(B, N, Z, H, D, C, O, dx, invariant_id, use_window, precision, d_true=0, h_true=0, variants=(0, 0),
+              masks=None):
+    """``variants``: (forward, backward) ENF_VARIANT_*; ``masks``: None or (int32 device tensor, "write" | "read", signals)."""
     d = EnfDesc()
     d.B, d.N, d.Z, d.H, d.D, d.C, d.O, d.dx = int(B), int(N), int(Z), int(H), int(D), int(C), int(O), int(dx)
     d.invariant_id, d.use_window, d.precision = int(invariant_id), int(bool(use_window)), int(precision)
     d.d_true, d.h_true = int(d_true), int(h_true)
+    d.pair_fwd_variant, d.pair_bwd_variant = int(variants[0]), int(variants[1])
+    if masks is not None:
+        buf, mode, signals = masks
+        d.relu_masks, d.mask_mode, d.mask_signals = buf.data_ptr(), MASK_MODE[mode], int(signals)
     return d

@@ -1,7 +1,10 @@
 // enf_api.hip -- the C-ABI of include/enf_hip.h: validation, workspace carving, kernel sequencing.
-// No allocation, no host synchronisation, no global state besides one-time kernel attributes.
+// No device allocation, no host synchronisation, no settings: a call depends on its arguments only.  The host-side
+// bookkeeping that exists -- one side stream per device and the pending side-stream work per (device, workspace) -- is
+// keyed by what the caller passes, so calls on different workspaces / streams / devices / threads do not interact.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <unordered_map>
 #include "enf_layout.h"
 
 extern "C" {
@@ -25,7 +28,8 @@ extern "C" const char* enf_strerror(int code) {
     case ENF_OK: return "ok";
     case ENF_EINVAL: return "invalid argument (null pointer or non-positive size)";
     case ENF_EINVARIANT: return "Unknown invariant type";
-    case ENF_EUNSUPPORTED: return "shape not in the compiled kernel set (num_hidden in {64,128}, num_heads in {1,2}, num_out <= 32)";
+    case ENF_EUNSUPPORTED: return "shape not in the compiled kernel set (num_hidden 64 or 128 after padding; num_heads 1, 2, or 4 at num_hidden 64; "
+                                  "num_out <= 32; ball / ball_lat at num_hidden 64 only)";
     case ENF_EWORKSPACE: return "workspace too small";
     case ENF_ELAUNCH: return "HIP launch failed";
     case ENF_EDIM: return "coordinate / pose width inconsistent with the invariant";
@@ -58,6 +62,10 @@ extern "C" int enf_check_desc(const EnfDesc* d) {
   if (d->h_true < 0 || d->h_true > d->H) return ENF_EINVAL;
   if (d->O > 32) return ENF_EUNSUPPORTED;
   if (d->precision != ENF_PREC_F32 && d->precision != ENF_PREC_BF16) return ENF_EINVAL;
+  if (d->pair_fwd_variant < ENF_VARIANT_AUTO || d->pair_fwd_variant > ENF_VARIANT_ZFOLD) return ENF_EINVAL;
+  if (d->pair_bwd_variant < ENF_VARIANT_AUTO || d->pair_bwd_variant > ENF_VARIANT_ZFOLD) return ENF_EINVAL;
+  if (d->mask_mode < ENF_MASK_OFF || d->mask_mode > ENF_MASK_READ || d->mask_signals < 0) return ENF_EINVAL;
+  if (d->mask_mode != ENF_MASK_OFF && !d->relu_masks) return ENF_EINVAL;
   return ENF_OK;
 }
 
@@ -71,38 +79,62 @@ extern "C" size_t enf_workspace_bytes(const EnfDesc* d) {
   return enf_workspace(enf_dims(d)).total;
 }
 
-// One side stream per process for work that can overlap the caller's stream (created on first use; ENF_SIDE_STREAM=0
-// disables it).  Fork / join is by events, so the caller's stream order is preserved; the mutex keeps concurrent host
-// threads from interleaving their record / wait pairs on the shared events.
-struct SideStream { hipStream_t s; hipEvent_t fork, join; std::mutex mu; bool pending = false; };
-static SideStream* side_stream() {
-  static SideStream* S = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    const char* e = getenv("ENF_SIDE_STREAM");
-    if (!(e && e[0] == '0')) {
-      SideStream* t = new SideStream();
-      if (hipStreamCreateWithFlags(&t->s, hipStreamNonBlocking) == hipSuccess &&
-          hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess &&
-          hipEventCreateWithFlags(&t->join, hipEventDisableTiming) == hipSuccess)
-        S = t;
-      else
-        delete t;
-    }
+// Side streams.  Work that can overlap the caller's stream (the z-fold backward's per-latent matrices) runs on ONE side
+// stream per device, created at the first call that needs it on that device; ENF_SIDE_STREAM=0 in the environment
+// disables it.  Fork / join is by events, so the caller's stream order is preserved.  What a forward leaves pending for
+// its backward (ENF_STAGE_PREPARE_BWD) is recorded against the WORKSPACE it was prepared in, with an event of its own:
+// only a call on that workspace sees it.  One mutex per device keeps host threads from interleaving their record / wait
+// pairs on the shared fork event.
+struct SidePending { hipEvent_t join = nullptr; bool pending = false; };
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr;
+  std::mutex mu;
+  std::unordered_map<const void*, SidePending> ws;     // by workspace base address
+  // the entry of a workspace (created on demand; entries without pending work are recycled beyond 64 workspaces)
+  SidePending* entry(const void* workspace) {
+    auto it = ws.find(workspace);
+    if (it != ws.end()) return &it->second;
+    if (ws.size() >= 64)
+      for (auto j = ws.begin(); j != ws.end();) {
+        if (!j->second.pending) { (void)hipEventDestroy(j->second.join); j = ws.erase(j); } else ++j;
+      }
+    SidePending e;
+    if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return &ws.emplace(workspace, e).first->second;
   }
-  return S;
+};
+static constexpr int ENF_MAX_DEVICES = 64;
+static SideStream* side_stream() {      // of the calling thread's current device, or nullptr
+  static std::mutex table_mu;
+  static SideStream* table[ENF_MAX_DEVICES] = {};
+  static bool tried[ENF_MAX_DEVICES] = {};
+  static const bool enabled = [] { const char* e = getenv("ENF_SIDE_STREAM"); return !(e && e[0] == '0'); }();
+  int dev = 0;
+  if (!enabled || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ENF_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(table_mu);
+  if (!tried[dev]) {
+    tried[dev] = true;
+    SideStream* t = new SideStream();
+    if (hipStreamCreateWithFlags(&t->s, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess)
+      table[dev] = t;
+    else
+      delete t;
+  }
+  return table[dev];
 }
 
-// join side-stream work left pending by an earlier ENF_STAGE_PREPARE_BWD (no matching backward came) before `st`
-// touches the workspace regions it writes
-static int side_join_pending(hipStream_t st) {
+// join the side-stream work an earlier ENF_STAGE_PREPARE_BWD left pending on THIS workspace (no matching backward
+// came) before `st` touches the regions it writes
+static int side_join_pending(hipStream_t st, const void* workspace) {
   SideStream* side = side_stream();
   if (!side) return 0;
   std::lock_guard<std::mutex> lk(side->mu);
-  if (side->pending) {
-    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ENF_ELAUNCH;
-    side->pending = false;
+  auto it = side->ws.find(workspace);
+  if (it != side->ws.end() && it->second.pending) {
+    if (hipStreamWaitEvent(st, it->second.join, 0) != hipSuccess) return ENF_ELAUNCH;
+    it->second.pending = false;
   }
   return 0;
 }
@@ -125,7 +157,7 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
   float* yb = ybar ? ybar : F(W.ybar);
   const bool zf = enf_use_zfold(m);
   float* ls = lse ? lse : F(W.lse);
-  if ((rc = side_join_pending(st))) return rc;
+  if ((rc = side_join_pending(st, workspace))) return rc;
   if ((stages & ENF_STAGE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
   if ((stages & (ENF_STAGE_PAIR | ENF_STAGE_FOLD)) &&
       (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
@@ -137,11 +169,14 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
     SideStream* side = side_stream();
     if (side) {
       std::lock_guard<std::mutex> lk(side->mu);
-      if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
-      if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, side->s))) return rc;
-      if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), side->s) != hipSuccess) return ENF_ELAUNCH;
-      if (hipEventRecord(side->join, side->s) != hipSuccess) return ENF_ELAUNCH;
-      side->pending = true;
+      SidePending* e = side->entry(workspace);
+      if (e) {
+        if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
+        if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, side->s))) return rc;
+        if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), side->s) != hipSuccess) return ENF_ELAUNCH;
+        if (hipEventRecord(e->join, side->s) != hipSuccess) return ENF_ELAUNCH;
+        e->pending = true;
+      }
     }
   }
   const bool tsave = (stages & ENF_STAGE_TAIL_SAVE) != 0;      // stash the tail's pre-activations for the backward that follows
@@ -182,36 +217,46 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
   char* ws = (char*)workspace;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
   const char* blob = (const char*)packed;
+  const bool zb = enf_use_zfold_bwd(m);
+  if (flags & ENF_BWD_ONLY_PAIR) {      // measurement hook: the pair kernel alone, on what a complete backward left behind
+    if ((rc = side_join_pending(st, workspace))) return rc;
+    if (hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
+    return enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr,
+                               zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, nullptr, st);
+  }
   // the latent table is recomputed (cheap) so the call does not depend on workspace contents, unless the
   // caller vouches that nothing has touched the workspace since the matching enf_forward
   if (!(flags & ENF_BWD_REUSE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st)))
     return rc;
   // z-fold backward: the per-latent matrices depend on the latent table only, so enf_wz_kernel runs on a side stream
   // (fork / join by events) beside the tail backward instead of in front of the pair kernel
-  const bool zb = enf_use_zfold_bwd(m);
   SideStream* side = zb ? side_stream() : nullptr;
   bool prepared = false;
   if (zb && side && (flags & ENF_BWD_REUSE_PREPARED) && (flags & ENF_BWD_REUSE_PROLOGUE)) {
     std::lock_guard<std::mutex> lk(side->mu);
-    prepared = side->pending;          // launched by the matching forward (ENF_STAGE_PREPARE_BWD)
+    auto it = side->ws.find(workspace);
+    prepared = it != side->ws.end() && it->second.pending;   // launched by the matching forward ON THIS WORKSPACE
   }
-  if (!prepared && (rc = side_join_pending(st))) return rc;
+  if (!prepared && (rc = side_join_pending(st, workspace))) return rc;
   if (zb && !prepared) {
+    bool forked = false;
     if (side) {
       std::lock_guard<std::mutex> lk(side->mu);
-      if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
-      if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, side->s))) return rc;
-      if (hipEventRecord(side->join, side->s) != hipSuccess) return ENF_ELAUNCH;
-    } else if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, st))) return rc;
+      SidePending* e = side->entry(workspace);
+      if (e) {
+        if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
+        if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, side->s))) return rc;
+        if (hipEventRecord(e->join, side->s) != hipSuccess) return ENF_ELAUNCH;
+        e->pending = true;              // until joined below: a failure in between leaves it for the next call's join
+        forked = true;
+      }
+    }
+    if (!forked && (rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, st))) return rc;
   }
   const bool treuse = (flags & ENF_BWD_REUSE_TAIL) && (flags & ENF_BWD_REUSE_PROLOGUE);
   if ((rc = enf_launch_tail(m, L, blob, ybar, nullptr, dout, F(W.dybar), F(W.delta), F(W.tail_act), 1, treuse ? 1 : 0, st))) return rc;
   if (!prepared && hipMemsetAsync(F(W.dlt), 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
-  if (zb && side) {
-    std::lock_guard<std::mutex> lk(side->mu);
-    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ENF_ELAUNCH;
-    side->pending = false;
-  }
+  if ((rc = side_join_pending(st, workspace))) return rc;      // the per-latent matrices (and, if prepared, the zeroed table)
   if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), lse, F(W.dybar), F(W.delta), F(W.dlt), nullptr,
                                 zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, nullptr, st))) return rc;
   if ((rc = enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st))) return rc;
@@ -239,24 +284,21 @@ extern "C" int enf_lt_layout_ext(const EnfDesc* d, int* off_ext, int* off_phase_
   return ENF_OK;
 }
 
-static int g_zfold_mode = -2;
-int enf_zfold_mode() {
-  if (g_zfold_mode == -2) {
-    const char* e = getenv("ENF_ZFOLD");
-    g_zfold_mode = !e ? -1 : (e[0] == '0' ? 0 : 1);
-  }
-  return g_zfold_mode;
+// ENF_ZFOLD / ENF_ZFOLD_BWD in the environment (read once, immutable afterwards): the variant ENF_VARIANT_AUTO resolves
+// to, for A/B runs of a whole program.  Per call: EnfDesc.pair_fwd_variant / pair_bwd_variant.
+int enf_zfold_env(int backward) {
+  static const int mode[2] = {
+      [] { const char* e = getenv("ENF_ZFOLD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }(),
+      [] { const char* e = getenv("ENF_ZFOLD_BWD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }()};
+  return mode[backward ? 1 : 0];
 }
-extern "C" void enf_set_zfold(int mode) { g_zfold_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
-static int g_zfold_bwd_mode = -2;
-int enf_zfold_bwd_mode() {
-  if (g_zfold_bwd_mode == -2) {
-    const char* e = getenv("ENF_ZFOLD_BWD");
-    g_zfold_bwd_mode = !e ? -1 : (e[0] == '0' ? 0 : 1);
-  }
-  return g_zfold_bwd_mode;
+
+extern "C" int enf_pair_variant(const EnfDesc* d, int backward) {
+  const int rc = enf_check_desc(d);
+  if (rc) return rc;
+  const EnfDims m = enf_dims(d);
+  return (backward ? enf_use_zfold_bwd(m) : enf_use_zfold(m)) ? ENF_VARIANT_ZFOLD : ENF_VARIANT_LATENT_SPLIT;
 }
-extern "C" void enf_set_zfold_bwd(int mode) { g_zfold_bwd_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
 
 extern "C" size_t enf_pair_scratch_bytes(const EnfDesc* d) {
   if (enf_check_desc(d)) return 0;
@@ -281,17 +323,10 @@ extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstr
                              (hipStream_t)stream);
 }
 
-extern "C" void enf_pair_fwd_set_masks(unsigned* masks, int mode, int mask_B);
-extern "C" void enf_pair_bwd_set_masks(const unsigned* masks, int mask_B);
 extern "C" size_t enf_relu_mask_bytes(const EnfDesc* d) {
   if (enf_check_desc(d) != ENF_OK) return 0;
-  return (size_t)d->B * d->Z * ((d->N + 15) / 16) * 2 * 64 * sizeof(unsigned);
-}
-extern "C" int enf_set_relu_masks(void* masks, int mode, int mask_signals) {
-  if (mode < 0 || mode > 2 || (mode && !masks)) return ENF_EINVAL;
-  enf_pair_fwd_set_masks(mode ? (unsigned*)masks : nullptr, mode, mask_signals);
-  enf_pair_bwd_set_masks(mode == 2 ? (const unsigned*)masks : nullptr, mask_signals);
-  return ENF_OK;
+  const size_t signals = d->mask_signals > 0 ? d->mask_signals : d->B;
+  return signals * d->Z * ((d->N + 15) / 16) * 2 * 64 * sizeof(unsigned);
 }
 
 extern "C" int enf_pair_backward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,

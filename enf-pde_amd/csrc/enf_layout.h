@@ -33,6 +33,9 @@ struct EnfDims {
   int KB;      // D/32   in/out blocks of a D-wide activation
   int KBH;     // HD/32
   int OB;      // ceil(O/32) output blocks of the last layer
+  // per-call options (EnfDesc): requested pair-kernel variants (ENF_VARIANT_*), relu masks
+  int var_fwd, var_bwd, mask_mode, mask_B;
+  unsigned* masks;
 };
 
 ENF_HD inline int enf_inv_dim(int inv, int dx) {
@@ -85,6 +88,10 @@ inline EnfDims enf_dims(const EnfDesc* d) {
   m.Ht = d->h_true > 0 ? d->h_true : d->H;
   m.I = enf_inv_dim(m.inv, m.dx); m.dp = enf_inv_pose_dim(m.inv, m.dx);
   m.HD = m.H * m.D; m.KB = m.D / 32; m.KBH = m.HD / 32; m.OB = (m.O + 31) / 32;
+  m.var_fwd = d->pair_fwd_variant; m.var_bwd = d->pair_bwd_variant;
+  m.masks = (unsigned*)d->relu_masks;
+  m.mask_mode = m.masks ? d->mask_mode : ENF_MASK_OFF;
+  m.mask_B = d->mask_signals > 0 ? d->mask_signals : d->B;
   return m;
 }
 
@@ -183,13 +190,15 @@ ENF_HD inline int enf_lt_off_c(int H, int D) { return 2 * H * D + 8; }
 // into ONE per-latent D x D matrix  W_zh = (Wgamma_h diag(v0_zh) + Wbeta_h) AM  (no nonlinearity
 // sits between them), built by enf_wz_kernel into `wz` before the pair kernel runs.  It needs
 // enough 128-query workgroups to fill the chip; below that the latent-split variant runs.
-// ENF_ZFOLD=0 / 1 in the environment, or enf_set_zfold(), forces the choice (tests).
-int enf_zfold_mode();   // enf_api.hip: -1 heuristic, 0 / 1 forced (ENF_ZFOLD in the environment, or enf_set_zfold)
+// EnfDesc.pair_fwd_variant forces the choice per call; for ENF_VARIANT_AUTO, ENF_ZFOLD=0 / 1 in the environment (read
+// once) replaces the heuristic (A/B runs of a whole program).
+int enf_zfold_env(int backward);   // enf_api.hip: -1 unset, 0 / 1
 inline bool enf_use_zfold(const EnfDims& m) {
   // one signal's folded matrices sit behind a buffer resource with 32-bit offsets: beyond 2 GB per signal (Z >= 32768
   // at D = 128, H = 2) only the latent-split variant can run
   if ((long long)m.Z * m.H * (long long)m.D * m.D * (m.bf16 ? 2 : 4) >= 0x7fffffffLL) return false;
-  const int mode = enf_zfold_mode();
+  if (m.var_fwd != ENF_VARIANT_AUTO) return m.var_fwd == ENF_VARIANT_ZFOLD;
+  const int mode = enf_zfold_env(0);
   if (mode >= 0) return mode == 1;
   return (long long)((m.N + 127) / 128) * m.B >= 192;
 }
@@ -198,10 +207,10 @@ ENF_HD inline size_t enf_wzu_bytes(int H, int D) { return (size_t)(D / 32) * 4 *
 
 // Backward counterpart (enf_pair_bwd_kernel<.., ZF = true>): one workgroup per latent, its 8 waves take 8 query
 // tiles at a time, so the per-latent matrices W_zh (both orientations) stream through the LDS ring shared by the
-// workgroup.  Needs enough latents to fill the chip.  ENF_ZFOLD_BWD=0/1 / enf_set_zfold_bwd() force the choice.
-int enf_zfold_bwd_mode();
+// workgroup.  Needs enough latents to fill the chip.  EnfDesc.pair_bwd_variant / ENF_ZFOLD_BWD=0/1 as for the forward.
 inline bool enf_use_zfold_bwd(const EnfDims& m) {
-  const int mode = enf_zfold_bwd_mode();
+  if (m.var_bwd != ENF_VARIANT_AUTO) return m.var_bwd == ENF_VARIANT_ZFOLD;
+  const int mode = enf_zfold_env(1);
   if (mode >= 0) return mode == 1;
   return (long long)m.B * m.Z >= 192;
 }

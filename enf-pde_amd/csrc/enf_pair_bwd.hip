@@ -22,6 +22,7 @@
 #endif
 #define ENF_ASM_LITE ENF_K3_LITE
 #include "enf_layout.h"
+#include "enf_launch.h"
 #include "enf_device.h"
 #include "enf_pair_common.h"
 
@@ -976,31 +977,21 @@ template <int D, int H, bool BF16, bool STORE, bool ZF>
 static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
   using SM = PairBwdSmem<D, H, BF16>;
   auto kern = enf_pair_bwd_kernel<D, H, BF16, STORE, ZF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL) != hipSuccess)
-      return ENF_ELAUNCH;
-    attr_set = true;
-  }
+  static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
+  if (!enf_lds_attr(reinterpret_cast<const void*>(kern), SM::TOTAL, attr_done)) return ENF_ELAUNCH;
   dim3 grid(ZF ? A.B * A.Z : (A.B * A.Z + NWAVES - 1) / NWAVES, A.nsplit);
   hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SM::TOTAL, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
-// (process-wide, not thread_local: the framework's backward runs on its autograd thread)
-static const unsigned* g_bwd_masks = nullptr;
-static int g_bwd_mask_B = 1;
-extern "C" void enf_pair_bwd_set_masks(const unsigned* masks, int mask_B) {   // consumed by the next STORE launch
-  g_bwd_masks = masks; g_bwd_mask_B = mask_B > 0 ? mask_B : 1;
-}
+// relu masks: per call (EnfDims.masks / mask_mode / mask_B, from the descriptor); read by the STORE instantiation only
 
 extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, const float* lse, const float* dybar, const float* delta, float* dlt,
                                    void* const* store, const char* wzt, const float* wzb, float* dxq, hipStream_t st) {
   PairBwdArgs A;
   A.dxq = dxq;
-  A.masks = store ? g_bwd_masks : nullptr; A.mask_B = g_bwd_mask_B;
-  if (store) g_bwd_masks = nullptr;
+  A.masks = store && m.mask_mode == ENF_MASK_READ ? m.masks : nullptr; A.mask_B = m.mask_B;
   const bool zf = !store && wzt && wzb && (size_t)m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
   A.wzt = wzt; A.wzb = wzb; A.inv_d = 1.0f / (float)m.Dt;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;

@@ -19,6 +19,7 @@
 // Weight panels stream L2 -> LDS by LDS-DMA through a 2-slot ring shared by the 8 waves.
 #include <hip/hip_runtime.h>
 #include "enf_layout.h"
+#include "enf_launch.h"
 #include "enf_device.h"
 #include "enf_pair_common.h"
 
@@ -385,12 +386,8 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   constexpr int NW = PairWaves<ZFOLD>::NW;
   using SM = PairSmem<D, H, BF16, NW>;
   auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD, MASKS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL) != hipSuccess)
-      return ENF_ELAUNCH;
-    attr_set = true;
-  }
+  static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
+  if (!enf_lds_attr(reinterpret_cast<const void*>(kern), SM::TOTAL, attr_done)) return ENF_ELAUNCH;
   dim3 grid((A.N + 16 * A.qg - 1) / (16 * A.qg), A.B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), SM::TOTAL, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
@@ -399,12 +396,7 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
 extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
 
 // wz / wzb: scratch for the z-fold variant (enf_workspace: W.wz, W.wzb), or NULL for the latent-split variant
-// (process-wide, not thread_local: the framework's backward runs on its autograd thread)
-static unsigned* g_fwd_masks = nullptr;
-static int g_fwd_mask_mode = 0, g_fwd_mask_B = 1;
-extern "C" void enf_pair_fwd_set_masks(unsigned* masks, int mode, int mask_B) {   // consumed by the next pair launch
-  g_fwd_masks = masks; g_fwd_mask_mode = masks ? mode : 0; g_fwd_mask_B = mask_B > 0 ? mask_B : 1;
-}
+// relu masks: per call (EnfDims.masks / mask_mode / mask_B, from the descriptor)
 
 extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
                                    const float* lt, float* ybar, float* lse, char* wz, float* wzb, char* wzu,
@@ -412,8 +404,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   PairFwdArgs A;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu; A.inv_d = 1.0f / (float)m.Dt;
   A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
-  A.masks = g_fwd_masks; A.mask_mode = run_pair ? g_fwd_mask_mode : 0; A.mask_B = g_fwd_mask_B;
-  if (run_pair) { g_fwd_masks = nullptr; g_fwd_mask_mode = 0; }
+  A.masks = m.masks; A.mask_mode = run_pair ? m.mask_mode : 0; A.mask_B = m.mask_B;
   // as many latent splits as there are latents to split (up to 8); the rest of the 8 waves take more queries
   int zs = 1;
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "enf_layout.h"
+#include "enf_launch.h"
 #include "enf_device.h"
 
 struct TailArgs {
@@ -356,14 +357,10 @@ static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
   if (la2_mode < 0) { const char* e = getenv("ENF_TAIL_LA2"); la2_mode = e ? (e[0] == '0' ? 0 : 1) : 2; }
   const bool la2 = la2_mode == 2 ? grid.x <= 256 : la2_mode == 1;
   // opt: forward -> stash the pre-activations (SAVE); backward -> they are stashed, skip the recompute
-  static bool attr_done[2][2][2] = {};       // [bwd][la2][opt] (this function is one instantiation per D, H, BF16)
+  static EnfAttrBits attr_done[2][2][2];     // [bwd][la2][opt] (this function is one instantiation per D, H, BF16), one bit per device
   auto go = [&](void (*kern_ptr)(TailArgs)) -> int {
     const int smem = la2 ? T::SMEM3 : T::SMEM;
-    if (!attr_done[bwd][la2][opt]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-        return ENF_ELAUNCH;
-      attr_done[bwd][la2][opt] = true;
-    }
+    if (!enf_lds_attr(reinterpret_cast<const void*>(kern_ptr), smem, attr_done[bwd][la2][opt])) return ENF_ELAUNCH;
     hipLaunchKernelGGL(kern_ptr, grid, dim3(NTHREADS), smem, st, A);
     return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
   };

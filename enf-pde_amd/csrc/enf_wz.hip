@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "enf_layout.h"
+#include "enf_launch.h"
 #include "enf_device.h"
 
 struct WzArgs {
@@ -196,12 +197,8 @@ template <int D, int H, bool BF16>
 static int launch_wz(const WzArgs& A, hipStream_t st) {
   constexpr int PB = D * D * (BF16 ? 2 : 4);
   auto kern = enf_wz_kernel<D, H, BF16>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PB) != hipSuccess)
-      return ENF_ELAUNCH;
-    attr_set = true;
-  }
+  static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
+  if (!enf_lds_attr(reinterpret_cast<const void*>(kern), PB, attr_done)) return ENF_ELAUNCH;
   // waves = COMBOS (head, block) roles x a number of latent lanes; each wave sweeps BZ / lanes latents
   constexpr int COMBOS = H * (D / 32);
   // the backward's call (both orientations) runs on the side stream beside the tail kernels and is off the critical

@@ -85,7 +85,7 @@ class _EnfFunction(torch.autograd.Function):
         lib = _lib.load()
         B, Z = p.shape[0], p.shape[1]
         N = x.shape[1]
-        desc = model._desc(B, N, Z)
+        desc = model._desc(B, N, Z, masks=model._masks)
         xb, xstride = model._x_arg(x)
         p_, a_ = p.contiguous(), a.contiguous()
         s_ = sigma.contiguous() if sigma is not None else None
@@ -98,8 +98,8 @@ class _EnfFunction(torch.autograd.Function):
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         # a backward follows when an input needs a gradient: stash the tail's pre-activations for it (ENF_STAGE_TAIL_SAVE)
         ctx.tail_saved = any(ctx.needs_input_grad[1:4])
-        _lib.check(lib.enf_forward_stages(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
-                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | (16 if ctx.tail_saved else 0), st))
+        _lib.launch(dev, lib.enf_forward_stages, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
+                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | (16 if ctx.tail_saved else 0), st)
         ctx.ws_tag = model._ws_touch(ws)      # backward may reuse the latent table if nothing else used the workspace
         ctx.model = model
         ctx.has_sigma = sigma is not None
@@ -127,9 +127,9 @@ class _EnfFunction(torch.autograd.Function):
         reuse = 1 if model._ws_tag(ws) == ctx.ws_tag else 0          # ENF_BWD_REUSE_PROLOGUE
         if reuse and ctx.tail_saved:
             reuse |= 2                                               # ENF_BWD_REUSE_TAIL
-        _lib.check(lib.enf_backward_latents_ex(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(p_), _ptr(a_), _ptr(sigma),
+        _lib.launch(dev, lib.enf_backward_latents_ex, ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(p_), _ptr(a_), _ptr(sigma),
                                                _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
-                                               _ptr(dsig), _ptr(ws), ws.numel(), reuse, st))
+                                               _ptr(dsig), _ptr(ws), ws.numel(), reuse, st)
         model._ws_touch(ws)
         return None, dp, da, (dsig if ctx.has_sigma else None), None, None
 
@@ -140,6 +140,8 @@ class EquivariantCrossAttentionNeF:
     Args mirror the Flax module's fields (NEF:85-96); ``precision`` ("bf16" | "f32") selects
     the MFMA arithmetic of the per-pair contractions (ENF_PREC_*).
     """
+
+    default_pair_variants = ("auto", "auto")
 
     def __init__(self, num_hidden, num_heads, num_layers, num_out, latent_dim, cross_attn_invariant,
                  self_attn_invariant=None, embedding_type="rff", embedding_freq_multiplier=(0.05, 0.1),
@@ -181,14 +183,20 @@ class EquivariantCrossAttentionNeF:
         self._ws_cache = {}
         self._ws_gen = 0
         self._ws_tags = {}
+        self.pair_variants = None               # (forward, backward) pair-kernel variant of this model's calls (_lib.VARIANT
+                                                # keys); None = the class default below (tests flip it to cover both kernels)
+        self._masks = None                      # (buffer, "write" | "read", signals) inside relu_masks(), else None
 
     # ------------------------------------------------------------------ descriptors / buffers
-    def _desc(self, B, N, Z):
+    def _desc(self, B, N, Z, masks=None):
+        """The call descriptor; ``masks`` = a (buffer, mode, signals) triple for calls whose pair kernels take relu masks."""
         inv = self.cross_attn_invariant
         return _lib.make_desc(B, N, Z, self._Hp, self._Dp, self.latent_dim, self.num_out,
                               inv.num_x_pos_dims, inv.kernel_id, self.use_gaussian_window, _lib.PREC[self.precision],
                               d_true=self.num_hidden if self._Dp != self.num_hidden else 0,
-                              h_true=self.num_heads if self._Hp != self.num_heads else 0)
+                              h_true=self.num_heads if self._Hp != self.num_heads else 0,
+                              variants=tuple(_lib.VARIANT[v] for v in (self.pair_variants or self.default_pair_variants)),
+                              masks=masks)
 
     def _workspace(self, desc, device):
         # one cached scratch buffer per (shape, stream); the autograd graph never keeps it alive
@@ -313,7 +321,7 @@ class EquivariantCrossAttentionNeF:
         blob = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
         arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.enf_pack_weights(ctypes.byref(desc), arr, _ptr(blob), st))
+        _lib.launch(dev, lib.enf_pack_weights, ctypes.byref(desc), arr, _ptr(blob), st)
         self._pack_cache["k"] = (key, blob, ts)   # keep the fp32 sources alive until the pack kernels ran
         return blob
 
@@ -379,19 +387,21 @@ class EquivariantCrossAttentionNeF:
         return torch.empty(int(_lib.load().enf_relu_mask_bytes(ctypes.byref(desc))) // 4, device=device, dtype=torch.int32)
 
     def relu_masks(self, buf, mode, signals):
-        """Context manager: the next pair-kernel forward (any path) WRITES ("write") the relu masks of its pre-activations
-        into ``buf``, or the next forward and the next weight-gradient backward READ ("read") them -- relu linearised at the
-        point the masks were taken, for signals b, b + signals, ... alike (include/enf_hip.h: enf_set_relu_masks)."""
+        """Context manager: inside it, THIS model's pair-kernel forwards (any path) WRITE ("write") the relu masks of their
+        pre-activations into ``buf``, or its forwards and the weight-gradient backwards of those forwards READ ("read") them
+        -- relu linearised at the point the masks were taken, for signals b, b + signals, ... alike (include/enf_hip.h:
+        EnfDesc.mask_mode).  The masks travel in each call's descriptor: other models and streams are not affected."""
         import contextlib
-        lib = _lib.load()
+        if mode not in ("write", "read"):
+            raise ValueError("mode must be 'write' or 'read'")
 
         @contextlib.contextmanager
         def cm():
-            _lib.check(lib.enf_set_relu_masks(_ptr(buf), {"write": 1, "read": 2}[mode], int(signals)))
+            prev, self._masks = self._masks, (buf, mode, int(signals))
             try:
                 yield buf
             finally:
-                lib.enf_set_relu_masks(None, 0, 1)
+                self._masks = prev
         return cm()
 
     @torch.no_grad()
@@ -418,7 +428,7 @@ class EquivariantCrossAttentionNeF:
         x, p_, a_ = x.float(), p.float().contiguous(), a.float().contiguous()
         s_ = sigma.float().reshape(p_.shape[0], p_.shape[1], 1).contiguous() if sigma is not None else None
         B, Z, N, dev = p_.shape[0], p_.shape[1], x.shape[1], p_.device
-        desc = self._desc(B, N, Z)
+        desc = self._desc(B, N, Z, masks=self._masks)
         xb, xstride = self._x_arg(x)
         HD = self._Hp * self._Dp
         out = torch.empty((B, N, self.num_out), device=dev, dtype=torch.float32)
@@ -426,18 +436,18 @@ class EquivariantCrossAttentionNeF:
         lse = torch.empty((B, N, self._Hp), device=dev, dtype=torch.float32)
         ws = self._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.enf_forward_stages(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
-                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16 | _PREP, st))   # + TAIL_SAVE (+ PREPARE_BWD)
+        _lib.launch(dev, lib.enf_forward_stages, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
+                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16 | _PREP, st)   # + TAIL_SAVE (+ PREPARE_BWD)
         tgt = target.float().contiguous()
         if tgt.shape != out.shape:
             raise AssertionError(f"target has shape {tuple(tgt.shape)}, expected {tuple(out.shape)}")
         loss = loss_out if loss_out is not None else torch.zeros(1, device=dev, dtype=torch.float32)
         dout = torch.empty_like(out)
-        _lib.check(lib.enf_mse_value_grad(_ptr(out), _ptr(tgt), out.numel(), float(grad_scale), _ptr(dout), _ptr(loss), st))
+        _lib.launch(dev, lib.enf_mse_value_grad, _ptr(out), _ptr(tgt), out.numel(), float(grad_scale), _ptr(dout), _ptr(loss), st)
         dp, da = torch.empty_like(p_), torch.empty_like(a_)
         dsig = torch.empty((B, Z, 1), device=dev, dtype=torch.float32)
-        _lib.check(lib.enf_backward_latents_ex(ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_),
+        _lib.launch(dev, lib.enf_backward_latents_ex, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_),
                                                _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
-                                               _ptr(dsig), _ptr(ws), ws.numel(), 1 | 2 | (_PREP >> 3), st))   # latent table, tail stash (, side work) are the forward's
+                                               _ptr(dsig), _ptr(ws), ws.numel(), 1 | 2 | (_PREP >> 3), st)   # latent table, tail stash (, side work) are the forward's
         self._ws_touch(ws)
         return loss, dp, da, (dsig if sigma is not None else None)

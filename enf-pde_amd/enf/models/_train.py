@@ -143,20 +143,21 @@ class _PairFunction(torch.autograd.Function):
         Z = lt.shape[0] // B
         H, D = model._Hp, model._Dp
         dev = lt.device
-        desc = model._desc(B, N, Z)
+        ctx.masks = getattr(model, "_masks", None)       # relu masks of this call (model.relu_masks); its backward replays them
+        desc = model._desc(B, N, Z, masks=ctx.masks) if ctx.masks is not None else model._desc(B, N, Z)
         xb, xstride = model._x_arg(x)
         lt_ = lt.detach().contiguous()
         effc = [t.detach().to(torch.float32).contiguous() for t in eff]
         blob = torch.empty(int(lib.enf_packed_weight_bytes(ctypes.byref(desc))), device=dev, dtype=torch.uint8)
         arr = (ctypes.c_void_p * len(effc))(*[t.data_ptr() for t in effc])
         st = _stream(dev)
-        _lib.check(lib.enf_pack_pair(ctypes.byref(desc), arr, _ptr(blob), st))
+        _lib.launch(dev, lib.enf_pack_pair, ctypes.byref(desc), arr, _ptr(blob), st)
         ybar = torch.empty((B, N, H * D), device=dev, dtype=torch.float32)
         lse = torch.empty((B, N, H), device=dev, dtype=torch.float32)
         nscr = int(lib.enf_pair_scratch_bytes(ctypes.byref(desc)))
         scratch = torch.empty(nscr, device=dev, dtype=torch.uint8) if nscr else None
-        _lib.check(lib.enf_pair_forward(ctypes.byref(desc), _ptr(xb), xstride, _ptr(lt_), _ptr(blob), _ptr(ybar),
-                                        _ptr(lse), _ptr(scratch), nscr, st))
+        _lib.launch(dev, lib.enf_pair_forward, ctypes.byref(desc), _ptr(xb), xstride, _ptr(lt_), _ptr(blob), _ptr(ybar),
+                                        _ptr(lse), _ptr(scratch), nscr, st)
         ctx.model, ctx.xstride, ctx.dims = model, xstride, (B, N, Z)
         ctx.need_w = any(ctx.needs_input_grad[3:])
         ctx.x_shape = tuple(x.shape)
@@ -186,8 +187,8 @@ class _PairFunction(torch.autograd.Function):
             return dxq          # (B, N, dx) also for a broadcast grid: autograd sums over the expand itself
         if not ctx.need_w:
             desc = model._desc(B, N, Z)
-            _lib.check(lib.enf_pair_backward_ex(ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(lt), _ptr(blob), _ptr(lse),
-                                                _ptr(dybar), _ptr(delta), _ptr(dlt), None, _ptr(dxq), st))
+            _lib.launch(dev, lib.enf_pair_backward_ex, ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(lt), _ptr(blob), _ptr(lse),
+                                                _ptr(dybar), _ptr(delta), _ptr(dlt), None, _ptr(dxq), st)
             return (dx_out(), dlt, None) + (None,) * _lib.ENF_NUM_PAIR_TENSORS
 
         bf16 = model.precision in ("bf16", "bfloat16")
@@ -195,6 +196,8 @@ class _PairFunction(torch.autograd.Function):
         ns = _lib.num_store(H)
         per_b = Z * N * D * ns * (2 if bf16 else 4)
         cb = max(1, min(B, STORE_BUDGET_BYTES // max(per_b, 1)))
+        if ctx.masks is not None and ctx.masks[1] == "read" and cb < B:      # the masks of signal b are those of b % signals
+            cb = max(ctx.masks[2], cb // ctx.masks[2] * ctx.masks[2])
         store = torch.empty((ns, cb * Z * N, D), device=dev, dtype=sdt)
         f32 = dict(device=dev, dtype=torch.float32)
         gAQ1, gAV1, gAF, gAM = (torch.zeros((D, D), **f32) for _ in range(4))
@@ -204,14 +207,19 @@ class _PairFunction(torch.autograd.Function):
         S = _lib
         for b0 in range(0, B, cb):
             nb = min(cb, B - b0)
-            desc = model._desc(nb, N, Z)
+            if ctx.masks is not None and ctx.masks[1] == "read":
+                if b0 % ctx.masks[2] or (nb % ctx.masks[2] and nb != B):
+                    raise _lib.EnfError("activation-store chunks must hold whole groups of mask_signals signals")
+                desc = model._desc(nb, N, Z, masks=ctx.masks)
+            else:
+                desc = model._desc(nb, N, Z)
             P = nb * Z * N
             sl = [store[i, :P] for i in range(ns)]
             arr = (ctypes.c_void_p * ns)(*[t.data_ptr() for t in sl])
             xo = xb if ctx.xstride == 0 else xb[b0:]
-            _lib.check(lib.enf_pair_backward_ex(ctypes.byref(desc), _ptr(xo), ctx.xstride, _ptr(lt[b0 * Z:]), _ptr(blob),
+            _lib.launch(dev, lib.enf_pair_backward_ex, ctypes.byref(desc), _ptr(xo), ctx.xstride, _ptr(lt[b0 * Z:]), _ptr(blob),
                                                 _ptr(lse[b0:]), _ptr(dybar[b0:]), _ptr(delta[b0:]), _ptr(dlt[b0 * Z:]),
-                                                arr, _ptr(dxq[b0:] if dxq is not None else None), st))
+                                                arr, _ptr(dxq[b0:] if dxq is not None else None), st)
             gAQ1 += _xt_dot(sl[S.ENF_S_EQ], sl[S.ENF_S_DA1]); gBQ1 += _col_sum(sl[S.ENF_S_DA1])
             gAV1 += _xt_dot(sl[S.ENF_S_EV], sl[S.ENF_S_DA2]); gBV1 += _col_sum(sl[S.ENF_S_DA2])
             gAF += _xt_dot(sl[S.ENF_S_G1], sl[S.ENF_S_DA3]); gBF += _col_sum(sl[S.ENF_S_DA3])

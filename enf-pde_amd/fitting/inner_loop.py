@@ -47,7 +47,7 @@ def meta_sgd_update(lat, grads, lrs, scale):
                                      g.stride(-2) if g.dim() > 1 else w, lr.numel(), 0)
         new[k] = out
     st = ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
-    _lib.check(lib.enf_meta_sgd_update(len(grads), segs, float(scale), st))
+    _lib.launch(out.device, lib.enf_meta_sgd_update, len(grads), segs, float(scale), st)
     return new
 
 

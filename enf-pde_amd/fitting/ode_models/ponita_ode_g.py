@@ -73,8 +73,8 @@ class _SepGconv(torch.autograd.Function):
         B, Z, C = a.shape
         J = kb.shape[-1]
         out = torch.empty_like(a)
-        _lib.check(lib.enf_ode_conv_forward(B, Z, J, C, _ptr(a), _ptr(kb), Z * J, J, _ptr(W),
-                                            _ptr(bias.contiguous() if bias is not None else None), _ptr(out), _stream(a.device)))
+        _lib.launch(a.device, lib.enf_ode_conv_forward, B, Z, J, C, _ptr(a), _ptr(kb), Z * J, J, _ptr(W),
+                                            _ptr(bias.contiguous() if bias is not None else None), _ptr(out), _stream(a.device))
         ctx.save_for_backward(a, kb, W)
         ctx.has_bias = bias is not None
         return out
@@ -90,10 +90,10 @@ class _SepGconv(torch.autograd.Function):
         da = dkb = dW = db = None
         if ctx.needs_input_grad[0]:       # d a[b,s,:] = sum_r g[b,r,:] * kernel[b,r,s,:]: the same contraction, (r, s) swapped
             da = torch.empty_like(a)
-            _lib.check(lib.enf_ode_conv_forward(B, Z, J, C, _ptr(g), _ptr(kb), J, Z * J, _ptr(W), _ptr(None), _ptr(da), st))
+            _lib.launch(a.device, lib.enf_ode_conv_forward, B, Z, J, C, _ptr(g), _ptr(kb), J, Z * J, _ptr(W), _ptr(None), _ptr(da), st)
         if ctx.needs_input_grad[1]:
             dkb = torch.empty_like(kb)
-            _lib.check(lib.enf_ode_conv_backward_basis(B, Z, J, C, _ptr(a), _ptr(g), _ptr(W), _ptr(dkb), st))
+            _lib.launch(a.device, lib.enf_ode_conv_backward_basis, B, Z, J, C, _ptr(a), _ptr(g), _ptr(W), _ptr(dkb), st)
         if ctx.needs_input_grad[2]:       # d W = kb^T (g (x) a) over the pair axis: a plain GEMM
             dW = _xt_dot(kb.reshape(-1, J), (g[:, :, None, :] * a[:, None, :, :]).reshape(-1, C))
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -120,7 +120,7 @@ class _PolyFeatures(torch.autograd.Function):
         F = lib.enf_ode_poly_num_features(I, degree)
         _lib.check(F if F < 0 else 0)
         out = torch.empty((P, F), device=x.device, dtype=torch.float32)
-        _lib.check(lib.enf_ode_poly_forward(P, I, degree, _ptr(x2), _ptr(out), _stream(x.device)))
+        _lib.launch(x.device, lib.enf_ode_poly_forward, P, I, degree, _ptr(x2), _ptr(out), _stream(x.device))
         ctx.save_for_backward(x2)
         ctx.degree, ctx.shape = degree, x.shape
         return out.view(*x.shape[:-1], F)
@@ -132,7 +132,7 @@ class _PolyFeatures(torch.autograd.Function):
         P, I = x2.shape
         g2 = g.reshape(P, -1).contiguous()
         dx = torch.empty_like(x2)
-        _lib.check(lib.enf_ode_poly_backward(P, I, ctx.degree, _ptr(x2), _ptr(g2), _ptr(dx), _stream(x2.device)))
+        _lib.launch(x2.device, lib.enf_ode_poly_backward, P, I, ctx.degree, _ptr(x2), _ptr(g2), _ptr(dx), _stream(x2.device))
         return dx.view(ctx.shape), None
 
 

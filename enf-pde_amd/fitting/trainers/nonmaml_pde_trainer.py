@@ -77,7 +77,7 @@ class NonMetaPDETrainer:
         loss, gw, ga = self.loss_and_grads(state, initial_state, traj_idx, mask)
         names = list(ga.keys())
         flat = gw + [ga[k] for k in names] + [loss.reshape(1)]
-        allreduce_mean_(flat)
+        allreduce_mean_(flat, weight=initial_state.shape[0])
         loss = flat[-1][0]
         nef_params, nef_opt_state = state.params["nef"], state.nef_opt_state
         if update_nef:

@@ -272,7 +272,7 @@ class MetaSGDPDETrainer:
                                      noise_pos=getattr(cfg.meta, "noise_pos_inner_loop", 0.0), generator=state.rng)
         lat_keys, lr_keys = list(lat0.keys()), list(lrs.keys())
         flat = grads["nef"] + [grads["autodecoder"][k] for k in lat_keys] + [grads["meta_sgd_lrs"][k] for k in lr_keys] + [loss.reshape(1)]
-        allreduce_mean_(flat)                                                    # one exchange per outer step
+        allreduce_mean_(flat, weight=img.shape[0])                               # one exchange per outer step
         loss = flat[-1][0]
         # nef: clip_by_global_norm(1.0) -> adamw                                  (pde_trainer.py:60-63,258-259)
         weights = self.nef.param_tensors(state.params["nef"])
@@ -370,7 +370,7 @@ class MetaSGDPDETrainer:
         grads = list(torch.autograd.grad(loss, leaves, allow_unused=True))
         grads = [torch.zeros_like(t) if g is None else g for t, g in zip(leaves, grads)]
         flat = grads + [loss.detach().reshape(1)]
-        allreduce_mean_(flat)
+        allreduce_mean_(flat, weight=trajectory.shape[0])
         new_leaves, ode_opt_state = self.ode_opt.update(grads, state.ode_opt_state, [t.detach() for t in leaves])
         params = dict(state.params, ode_params=_unflatten(state.params["ode_params"], new_leaves))
         return flat[-1][0], TrainState(params=params, nef_opt_state=state.nef_opt_state,
@@ -409,7 +409,7 @@ class MetaSGDPDETrainer:
                                      noise_pos=getattr(cfg.meta, "noise_pos_inner_loop", 0.0), generator=state.rng, terminal=terminal)
         lr_keys = list(lrs.keys())
         flat = grads["nef"] + [grads["meta_sgd_lrs"][k] for k in lr_keys] + side["ode"] + [loss.reshape(1)]
-        allreduce_mean_(flat)
+        allreduce_mean_(flat, weight=img.shape[0])
         weights = self.nef.param_tensors(state.params["nef"])
         new_w, nef_opt_state = self.nef_opt.update(clip_by_global_norm(grads["nef"], 1.0), state.nef_opt_state, weights)
         new_lrs, lr_state = self.meta_sgd_opt.update([grads["meta_sgd_lrs"][k] for k in lr_keys], state.meta_sgd_opt_state,

@@ -7,7 +7,10 @@
  * forward, one backward-to-latents, weight packing, and size queries.  Plain pointers and
  * sizes only; every buffer is owned by the caller and lives in device (HBM) memory; nothing
  * is allocated, freed or synchronised inside the library; all work is enqueued on `stream`
- * (a hipStream_t passed as void*).  Functions return 0 or a negative ENF_E* code.
+ * (a hipStream_t passed as void*; the calling thread's current device must be the stream's).  Functions return 0 or a
+ * negative ENF_E* code.  The library keeps no settings: a call depends on its arguments only, calls on different
+ * (workspace, stream) pairs are independent and may come from different host threads, models and devices.  A workspace
+ * is scratch of ONE call sequence at a time (the REUSE flags below tie a backward to the forward before it).
  *
  * Layouts (all fp32, C-contiguous, batch first):
  *   x      (B, N, dx)   query coordinates; x_bstride = element stride between signals
@@ -28,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ENF_ABI_VERSION 1
+#define ENF_ABI_VERSION 2
 
 /* cross-attention invariants: enf/steerable_attention/invariant/__init__.py:47-78 */
 enum {
@@ -46,15 +49,27 @@ enum {
 
 /* arithmetic of the per-pair contractions */
 enum {
-  ENF_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity mode) */
-  ENF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate (throughput mode) */
+  ENF_PREC_F32 = 0,  /* v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate (parity mode) */
+  ENF_PREC_BF16 = 1  /* v_mfma_f32_16x16x32_bf16: bf16 operands, fp32 accumulate (throughput mode) */
 };
+
+/* pair-kernel variant of a call: latent-split / unfolded, or z-fold (per-latent folded matrices) */
+enum {
+  ENF_VARIANT_AUTO = 0,          /* by problem size */
+  ENF_VARIANT_LATENT_SPLIT = 1,  /* forward: the 8 waves split Z; backward: one wave = one latent */
+  ENF_VARIANT_ZFOLD = 2          /* forward: >= 192 workgroups of 128 queries; backward: >= 192 latents */
+};
+
+/* relu masks of a call (see "Relu masks" below) */
+#define ENF_MASK_OFF 0
+#define ENF_MASK_WRITE 1
+#define ENF_MASK_READ 2
 
 enum {
   ENF_OK = 0,
   ENF_EINVAL = -1,       /* NULL pointer / non-positive size */
   ENF_EINVARIANT = -2,   /* unknown invariant id (reference: ValueError, invariant/__init__.py:78) */
-  ENF_EUNSUPPORTED = -3, /* shape outside the compiled kernel set (D in {64,128}, H in 1..4, ...) */
+  ENF_EUNSUPPORTED = -3, /* shape outside the compiled kernel set (D in {64,128}; H in {1,2}, 4 at D = 64; O <= 32) */
   ENF_EWORKSPACE = -4,   /* workspace too small */
   ENF_ELAUNCH = -5,      /* HIP launch error */
   ENF_EDIM = -6          /* dx / dp inconsistent with the invariant (reference asserts, :62,65) */
@@ -72,7 +87,13 @@ typedef struct EnfDesc {
   int32_t d_true;       /* 0, or the model's num_hidden when D is a zero-padded width (d_true < D): LayerNorm statistics and
                            the D^-1/2 logit scale use d_true; the caller pads every weight tensor with zeros (see
                            enf-pde_amd/enf/models/_pad.py).  Lets num_hidden 16 / 32 (config_diff_sphere.yaml) run on the D = 64 kernels */
-  int32_t reserved[3];
+  /* ---- per-call options.  Everything a call depends on is in its arguments: the library keeps no mutable settings. */
+  int32_t pair_fwd_variant; /* ENF_VARIANT_*: forward pair kernel.  enf_workspace_bytes / enf_pair_scratch_bytes depend on it */
+  int32_t pair_bwd_variant; /* ENF_VARIANT_*: backward pair kernel (the weight-gradient path always runs the unfolded one) */
+  int32_t mask_mode;        /* ENF_MASK_*: what the pair kernels of THIS call do with `relu_masks` */
+  int32_t mask_signals;     /* signals b, b + mask_signals, ... share the masks of signal b % mask_signals (0 = B) */
+  int32_t reserved;
+  void* relu_masks;         /* enf_relu_mask_bytes(d) bytes of device memory, or NULL with ENF_MASK_OFF */
 } EnfDesc;
 
 /* Weight tensors in the order `enf_pack_weights` expects them; names are the Flax tree of
@@ -130,9 +151,11 @@ int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float
                                   runs between PROLOGUE and PAIR, PAIR alone reuses what the workspace holds */
 #define ENF_STAGE_TAIL_SAVE 16u /* with ENF_STAGE_TAIL: stash the tail's pre-activations in the workspace; the backward
                                   that follows on the untouched workspace (ENF_BWD_REUSE_TAIL) then skips their recompute */
-#define ENF_STAGE_PREPARE_BWD 32u /* a backward on the same inputs follows: what it needs from the latent table alone (its
-                                  per-latent folded matrices, the zeroed gradient table) starts on the library's side stream
-                                  behind the pair kernel; pass ENF_BWD_REUSE_PREPARED to that backward */
+#define ENF_STAGE_PREPARE_BWD 32u /* a backward on the same inputs and WORKSPACE follows: what it needs from the latent table
+                                  alone (its per-latent folded matrices, the zeroed gradient table) starts on the device's
+                                  side stream behind the pair kernel; pass ENF_BWD_REUSE_PREPARED to that backward.  The
+                                  pending work is recorded against this workspace: any later call on the same workspace
+                                  joins it first, a call on another workspace neither sees nor consumes it */
 int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
                        const float* sigma, const void* packed, float* out, float* ybar, float* lse,
                        void* workspace, size_t workspace_bytes, unsigned stages, void* stream);
@@ -153,6 +176,10 @@ int enf_backward_latents(const EnfDesc* d, const float* x, int64_t x_bstride, co
 /* ENF_BWD_REUSE_PREPARED (with ENF_BWD_REUSE_PROLOGUE): that forward ran with ENF_STAGE_PREPARE_BWD: join its side-stream
  * work instead of repeating it (ignored when nothing is pending). */
 #define ENF_BWD_REUSE_PREPARED 4u
+/* ENF_BWD_ONLY_PAIR: measurement hook, the backward counterpart of enf_forward_stages(ENF_STAGE_PAIR): re-run ONLY the
+ * backward pair kernel (preceded by the zero-fill of the 2 MB gradient table it accumulates into) on the workspace a
+ * complete enf_backward_latents[_ex] call with the same arguments has just left; dp / da / dsigma are not written. */
+#define ENF_BWD_ONLY_PAIR 8u
 int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p,
                          const float* a, const float* sigma, const void* packed, const float* ybar,
                          const float* lse, const float* dout, float* dp, float* da, float* dsigma,
@@ -217,17 +244,13 @@ int enf_pair_backward_ex(const EnfDesc* d, const float* x, int64_t x_bstride, co
 /* Relu masks.  Second-order terms taken as finite differences of FIRST-order gradients (the outer MAML step,
  * pde_trainer.py:255) converge to the DISTRIBUTIONAL second derivative: relu units whose sign changes between the two
  * perturbed points add a finite amount that automatic differentiation (relu'' = 0) never includes (20 % on the RFFNet
- * layer-0 weights in the tests).  With ENF_MASK_WRITE the next pair-kernel forward records, per pair and relu layer (the
- * two RFFNet layers), which pre-activations are positive; with ENF_MASK_READ the next pair-kernel forward and the next
- * enf_pair_backward[_ex] WITH an activation store use the relu LINEARISED at those masks (h = a where the bit is set)
- * instead of max(a, 0), for signals b, b + mask_signals, ... alike.  One 32-bit word per lane, 16-query tile, latent and
- * layer: enf_relu_mask_bytes(d) for the shape that WRITES them (same N, Z; B = mask_signals).  The setting is consumed
- * by those launches (one forward, one backward) and then reverts to ENF_MASK_OFF.  Process-wide state: one trainer. */
-#define ENF_MASK_OFF 0
-#define ENF_MASK_WRITE 1
-#define ENF_MASK_READ 2
+ * layer-0 weights in the tests).  With EnfDesc.mask_mode = ENF_MASK_WRITE the pair-kernel forward of the call records, per
+ * pair and relu layer (the two RFFNet layers), which pre-activations are positive, into EnfDesc.relu_masks; with
+ * ENF_MASK_READ the pair-kernel forward of the call, and enf_pair_backward[_ex] / enf_backward_weights, use the relu
+ * LINEARISED at those masks (h = a where the bit is set) instead of max(a, 0), for signals b, b + mask_signals, ...
+ * alike.  One 32-bit word per lane, 16-query tile, latent and layer: enf_relu_mask_bytes(d) for the shape that WRITES
+ * them (same N, Z; B = mask_signals). */
 size_t enf_relu_mask_bytes(const EnfDesc* d);
-int enf_set_relu_masks(void* masks, int mode, int mask_signals);
 
 /* Reconstruction loss of the inner loop and its gradient in one pass (pde_trainer.py:185):
  *   *loss += mean((out - target)^2)   (the caller zeroes *loss),   dout = 2 (out - target) / n * grad_scale  (dout may be NULL) */
@@ -272,11 +295,9 @@ int enf_ode_poly_num_features(int I, int degree);
 int enf_ode_poly_forward(int64_t P, int I, int degree, const float* x, float* feat, void* stream);
 int enf_ode_poly_backward(int64_t P, int I, int degree, const float* x, const float* dfeat, float* dx, void* stream);
 
-/* Forward pair-kernel variant: -1 = choose by problem size (default), 0 = latent-split, 1 = z-fold
- * (DESIGN.md 5).  Also settable with ENF_ZFOLD=0/1 in the environment.  Affects enf_workspace_bytes /
- * enf_pair_scratch_bytes: size buffers after setting it.  Process-wide; meant for tests and benchmarks. */
-void enf_set_zfold(int mode);
-void enf_set_zfold_bwd(int mode);   /* same for the backward pair kernel (ENF_ZFOLD_BWD in the environment) */
+/* The pair-kernel variant a call with this descriptor runs (ENF_VARIANT_AUTO resolved): ENF_VARIANT_LATENT_SPLIT or
+ * ENF_VARIANT_ZFOLD; `backward` = 0 for the forward kernel, 1 for the backward kernel.  Negative ENF_E* on a bad descriptor. */
+int enf_pair_variant(const EnfDesc* d, int backward);
 
 #ifdef __cplusplus
 }

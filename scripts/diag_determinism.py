@@ -31,8 +31,8 @@ for rnd in range(rounds):
     order.shuffle(keys)
     for c, zf, zb in keys:
         cfg, precision, prm, x, p, a, s, w = cases[c]
-        lib.enf_set_zfold(zf); lib.enf_set_zfold_bwd(zb)
         nef = T.build_nef(cfg, precision)
+        nef.pair_variants = (("latent_split", "z_fold")[zf], ("latent_split", "z_fold")[zb])
         res = T.hip_grads(cuda, nef, prm, x, p, a, s, w)
         if (c, zf, zb) not in first:
             first[(c, zf, zb)] = res

@@ -1,13 +1,12 @@
 """Dev diagnostic: which ingredient of sweep case 3 (ponita, D=64, H=2, B=1, N=87, Z=11, bf16, unfolded backward) makes its
 gradients depend on stale memory.  Each configuration: repeated runs with junk written into freed allocator blocks in between."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import tests.test_gpu_backward as T
 from enf_pde_amd import _lib
 lib = _lib.load()
 cuda = torch.device("cuda:0")
-lib.enf_set_zfold(0); lib.enf_set_zfold_bwd(0)
 base = dict(inv="ponita", D=64, H=2, B=1, N=87, Z=11, prec="bf16", C=7, O=2)
 variants = [{}, {"inv": "rel_pos"}, {"H": 4}, {"H": 1}, {"D": 128}]
 for v in variants:
@@ -21,6 +20,7 @@ for v in variants:
         junk = [torch.randn(int(n), device=cuda) * 10 for n in np.random.default_rng(it).integers(1 << 10, 1 << 22, 12)]
         del junk
         nef = T.build_nef(cfg, c["prec"])
+        nef.pair_variants = ("latent_split", "latent_split")
         res = T.hip_grads(cuda, nef, prm, x, p, a, s, w)
         if first is None:
             first = res; continue

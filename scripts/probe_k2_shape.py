@@ -17,7 +17,7 @@ packed = nef.pack(params)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 for mode in (0, 1):
-    lib.enf_set_zfold(mode)
+    nef.pair_variants = (("latent_split", "z_fold")[mode], "auto")
     desc = nef._desc(B, N, Z)
     ws = torch.empty(int(lib.enf_workspace_bytes(ctypes.byref(desc))), device=dev, dtype=torch.uint8)
     out = torch.empty(B, N, bench.O, device=dev)
@@ -39,4 +39,3 @@ for mode in (0, 1):
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 30 * 1e3
     print(f"B={B} N={N} Z={Z} zfold={mode}: pair {res['pair']:.1f} us  fold(wz) {res['fold']:.1f} us")
-lib.enf_set_zfold(-1)

@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 nef, params, lat0, lrs, masks = bench.build(dev, "bf16")
 coords, img = bench.synth_fields(bench.B_PER_GPU, 100, dev)
 import os as _os
-if _os.environ.get("ZF"): _lib.load().enf_set_zfold(int(_os.environ["ZF"]))
+if _os.environ.get("ZF"): nef.pair_variants = (("latent_split", "z_fold")[int(_os.environ["ZF"])], "auto")
 r = bench.roofline_leg(nef, params, coords, dev, iters=3)
 torch.cuda.synchronize()
 lib = _lib.load()

@@ -22,19 +22,19 @@ def cuda():
 
 @pytest.fixture(params=["latent_split", "z_fold"])
 def pair_variant(request):
-    """Runs a test under both forward pair-kernel variants (enf_set_zfold, include/enf_hip.h)."""
-    from enf_pde_amd import _lib
-    lib = _lib.load()
-    lib.enf_set_zfold(1 if request.param == "z_fold" else 0)
+    """Runs a test under both forward pair-kernel variants (EnfDesc.pair_fwd_variant, include/enf_hip.h)."""
+    from enf_pde_amd.enf.models import EquivariantCrossAttentionNeF as NeF
+    prev = NeF.default_pair_variants
+    NeF.default_pair_variants = (request.param, prev[1])
     yield request.param
-    lib.enf_set_zfold(-1)
+    NeF.default_pair_variants = prev
 
 
 @pytest.fixture(params=["unfolded", "z_fold"])
 def bwd_variant(request):
-    """Runs a test under both backward pair-kernel variants (enf_set_zfold_bwd, include/enf_hip.h)."""
-    from enf_pde_amd import _lib
-    lib = _lib.load()
-    lib.enf_set_zfold_bwd(1 if request.param == "z_fold" else 0)
+    """Runs a test under both backward pair-kernel variants (EnfDesc.pair_bwd_variant, include/enf_hip.h)."""
+    from enf_pde_amd.enf.models import EquivariantCrossAttentionNeF as NeF
+    prev = NeF.default_pair_variants
+    NeF.default_pair_variants = (prev[0], "z_fold" if request.param == "z_fold" else "latent_split")
     yield request.param
-    lib.enf_set_zfold_bwd(-1)
+    NeF.default_pair_variants = prev

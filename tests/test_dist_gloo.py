@@ -26,6 +26,11 @@ def _worker(rank, world, port, q):
     lo, hi = shard_range(13, r, w)
     grads = [torch.full((5,), float(r + 1)), torch.arange(6, dtype=torch.float32).reshape(2, 3) * (r + 1)]
     allreduce_mean_(grads)
+    # unequal shards (13 signals over 2 ranks = 7 + 6): per-rank means weighted by the shard size give the job's mean
+    items = torch.arange(13, dtype=torch.float32) ** 2
+    wm = [items[lo:hi].mean().reshape(1)]
+    allreduce_mean_(wm, weight=hi - lo)
+    assert abs(wm[0].item() - items.mean().item()) < 1e-4
     # per-rank "work": each rank sums its shard; the job total must be the serial total
     part = torch.tensor([float(sum(range(lo, hi)))])
     dist.all_reduce(part)

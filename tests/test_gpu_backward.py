@@ -100,7 +100,7 @@ def test_random_shape_sweep(cuda, case, pair_variant, bwd_variant):
 def test_backward_is_reproducible(cuda, H, bwd_variant):
     """The same inputs give the same gradients run after run (up to the order of the atomic adds), with other work --
     and other contents of freed memory -- in between: the unfolded 64-wide bf16 kernel with two heads once differed by 1e-2
-    between runs (a start-up race, scripts/diag_k3_unfolded.py), far inside the oracle tolerance of this file."""
+    between runs (a start-up race, scripts/k3_race/diag_k3_unfolded.py), far inside the oracle tolerance of this file."""
     cfg = make_cfg("ponita", D=64, H=H, C=7, O=2, freq=(0.3, 0.6))
     prm = R.init_params(5, cfg, jitter=0.1)
     x, p, a, s = make_inputs(cfg, 1, 87, 11, 6)
@@ -133,22 +133,18 @@ def test_duplicate_waves_agree(cuda, D, H, precision):
     x, p, a, s = make_inputs(cfg, 1, N, 2, 6)
     w = np.random.default_rng(7).standard_normal((1, N, cfg["num_out"]))
     row = 16 * 64 + 16
+    nef = build_nef(cfg, precision)
+    nef.pair_variants = ("latent_split", "latent_split")
     with _lib.using(tl):
-        tl.enf_set_zfold(0)
-        tl.enf_set_zfold_bwd(0)
-        try:
-            for it in range(4):
-                hip_grads(cuda, build_nef(cfg, precision), prm, x, p, a, s, w)
-                buf = (ctypes.c_float * (64 * 8 * row))()
-                assert tl.enf_test_read_wave_sums(buf) == 0
-                sums = np.array(buf, dtype=np.float32).reshape(64, 8, row)
-                launched = sums[:, 0, 16 * 64 + 10] > 0                       # tiles swept by wave 0 of the workgroup
-                assert launched.sum() >= 32
-                assert (sums[launched][:, 1:, 16 * 64 + 9] == 1).all()         # every wave from 1 on worked on latent 1
-                ref = sums[launched][:, 1:2, :16 * 64 + H + 5]
-                dup = sums[launched][:, 2:, :16 * 64 + H + 5]
-                differ = (dup != ref).any(-1)
-                assert not differ.any(), (it, int(differ.sum()), "duplicate waves differ from wave 1; per wave", differ.sum(0).tolist())
-        finally:
-            tl.enf_set_zfold(-1)
-            tl.enf_set_zfold_bwd(-1)
+        for it in range(4):
+            hip_grads(cuda, nef, prm, x, p, a, s, w)
+            buf = (ctypes.c_float * (64 * 8 * row))()
+            assert tl.enf_test_read_wave_sums(buf) == 0
+            sums = np.array(buf, dtype=np.float32).reshape(64, 8, row)
+            launched = sums[:, 0, 16 * 64 + 10] > 0                       # tiles swept by wave 0 of the workgroup
+            assert launched.sum() >= 32
+            assert (sums[launched][:, 1:, 16 * 64 + 9] == 1).all()         # every wave from 1 on worked on latent 1
+            ref = sums[launched][:, 1:2, :16 * 64 + H + 5]
+            dup = sums[launched][:, 2:, :16 * 64 + H + 5]
+            differ = (dup != ref).any(-1)
+            assert not differ.any(), (it, int(differ.sum()), "duplicate waves differ from wave 1; per wave", differ.sum(0).tolist())

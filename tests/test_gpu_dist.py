@@ -72,3 +72,24 @@ def test_two_ranks_share_one_outer_step(cuda):
     # the first Adam step is lr * sign-ish(g): entries whose gradient is within rounding / finite-difference noise of zero
     # (the step size of the Hessian-vector differences is chosen per batch) may move the other way; the rest agree
     assert ((w - wa).abs() < 2e-4).float().mean() > 0.97 and ((o - oa).abs() < 2e-4).float().mean() > 0.97
+
+
+def test_bench_spawns_its_own_ranks(cuda):
+    """`bench.py --gpus 2` with no torchrun environment launches two ranks itself (here both on the one GPU, over gloo:
+    ENF_BENCH_SHARE_GPU=1, a rehearsal switch) and the line it prints says two ranks ran, with the outer step's all-reduce
+    inside the timed meta_step leg."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ENF_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2")
+    assert d["meta_step"]["n_gpus"] == 2 and "gloo" in d["meta_step"]["collective"] and d["meta_step"]["ms_per_step"] > 0
+    one = 16 * (4 * 512 + 4096)
+    assert abs(d["value"] - 2 * one * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]      # the whole job's points / time

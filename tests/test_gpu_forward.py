@@ -75,13 +75,9 @@ def test_variants_agree_at_full_size(cuda, precision):
     params = nef.load_params(prm, device=cuda)
     t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
     outs = []
-    lib = _lib.load()
-    try:
-        for mode in (0, 1):
-            lib.enf_set_zfold(mode)
-            outs.append(nef.apply(params, t(x), t(p), t(a), t(s)))
-    finally:
-        lib.enf_set_zfold(-1)
+    for mode in ("latent_split", "z_fold"):
+        nef.pair_variants = (mode, "auto")
+        outs.append(nef.apply(params, t(x), t(p), t(a), t(s)))
     ref, got = outs
     err = float((got - ref).abs().max() / ref.abs().max())
     assert torch.isfinite(got).all() and err < (2e-5 if precision == "f32" else 3e-2), err

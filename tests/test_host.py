@@ -4,6 +4,7 @@ reference interface (constructor keywords, parameter tree, latents, error behavi
 import ctypes
 import os
 import re
+import sys
 from types import SimpleNamespace as NS
 
 import numpy as np
@@ -28,13 +29,29 @@ def test_library_exports_every_declared_symbol(lib):
             "enf_strerror", "enf_check_desc", "enf_forward_stages"} <= declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.enf_abi_version() == 1
+    assert lib.enf_abi_version() == 2
 
 
 def test_desc_struct_matches_header():
     from enf_pde_amd import _lib
-    assert ctypes.sizeof(_lib.EnfDesc) == 16 * 4
     hdr = open(os.path.join(ROOT, "include", "enf_hip.h")).read()
+    # field by field against the header's struct (all int32_t but the trailing mask pointer)
+    body = hdr[hdr.index("typedef struct EnfDesc {"):hdr.index("} EnfDesc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for kind, names in re.findall(r"\b(int32_t|void\*)\s+([^;]+);", body):
+        fields += [(n.strip(), kind) for n in names.split(",")]
+    assert [n for n, _ in fields] == [f[0] for f in _lib.EnfDesc._fields_]
+    for (n, kind), (_, ctype) in zip(fields, _lib.EnfDesc._fields_):
+        assert ctype is (ctypes.c_void_p if kind == "void*" else ctypes.c_int32), n
+    assert ctypes.sizeof(_lib.EnfDesc) == 18 * 4 + 8 and _lib.EnfDesc.relu_masks.offset == 72
+    # the option enums of the binding are the header's
+    for table, prefix in ((_lib.VARIANT, "ENF_VARIANT_"), (_lib.PREC, "ENF_PREC_")):
+        for name, val in table.items():
+            m = re.search(prefix + name.upper() + r" = (\d)", hdr)
+            assert m is None or int(m.group(1)) == val, name
+    for name, val in _lib.MASK_MODE.items():
+        assert re.search(r"#define ENF_MASK_" + name.upper() + r" (\d)", hdr).group(1) == str(val)
     assert "ENF_NUM_TENSORS" in hdr and _lib.ENF_NUM_TENSORS == 46
     # enum order of the invariants is the binding's id table
     ids = re.findall(r"ENF_INV_([A-Z_]+) = (\d)", hdr)
@@ -70,6 +87,21 @@ def test_check_desc_and_error_mapping(lib):
     for bad in (_lib.make_desc(2, 100, 25, 2, 128, 32, 1, 3, 7, 1, 1), _lib.make_desc(2, 100, 25, 4, 64, 32, 1, 2, 8, 1, 1)):
         with pytest.raises((_lib.EnfError, NotImplementedError, AssertionError)):
             _lib.check(lib.enf_check_desc(ctypes.byref(bad)))
+    # per-call options are validated too: unknown variant, masks requested without a buffer
+    for kw in (dict(variants=(3, 0)), dict(variants=(0, -1))):
+        assert lib.enf_check_desc(ctypes.byref(_lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1, **kw))) == -1
+    nomask = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1)
+    nomask.mask_mode = 2
+    assert lib.enf_check_desc(ctypes.byref(nomask)) == -1
+    # the variant a descriptor resolves to, and the sizes that follow from it, depend on the descriptor alone
+    small, large = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1), _lib.make_desc(16, 4096, 64, 2, 128, 16, 1, 2, 0, 1, 1)
+    assert lib.enf_pair_variant(ctypes.byref(small), 0) == 1 and lib.enf_pair_variant(ctypes.byref(large), 0) == 2
+    assert lib.enf_pair_variant(ctypes.byref(small), 1) == 1 and lib.enf_pair_variant(ctypes.byref(large), 1) == 2
+    forced = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1, variants=(2, 2))
+    assert lib.enf_pair_variant(ctypes.byref(forced), 0) == 2 and lib.enf_pair_variant(ctypes.byref(forced), 1) == 2
+    assert lib.enf_pair_scratch_bytes(ctypes.byref(small)) == 0 < lib.enf_pair_scratch_bytes(ctypes.byref(forced))
+    assert lib.enf_workspace_bytes(ctypes.byref(forced)) > lib.enf_workspace_bytes(ctypes.byref(small))
+    assert lib.enf_pair_variant(ctypes.byref(small), 0) == 1                      # ... and nothing sticks between calls
     # NULL buffers are rejected before anything touches the (absent) GPU
     assert lib.enf_forward(ctypes.byref(ok), None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
 
@@ -297,3 +329,32 @@ def test_trainer_phase_schedule():
     assert fr.shape == (4, 4, 4, 1)
     ids = {int(f[0, 0, 0]) // 16 % 10 for f in fr}
     assert len(ids) == 2 and max(ids) < 6                                          # two distinct training frames
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """bench.py --gpus N must run N ranks or fail (it never reports an N-GPU line from another number of ranks)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and not r.stdout.strip()
+    import torch
+    if torch.cuda.device_count() < 2:        # no torchrun environment: it would spawn 2 ranks itself, but there are not 2 GPUs
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "GPU(s)" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_configs_cover_baseline_json():
+    import json
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert sorted(bench.CONFIGS) == list(range(1, len(base["configs"]) + 1))
+    c2 = bench.CONFIGS[bench.HEADLINE]
+    assert (c2["Z"], c2["grid"], c2["D"], c2["H"]) == (64, (64, 64), 128, 2)          # the metric's "64 latents x 64^2 grid"
+    assert bench.pair_flops(c2) == 494080 and bench.points_per_signal(c2) == 4 * 512 + 4096
+    assert bench.points_per_signal(bench.CONFIGS[5]) == 4 * 512 + 41 * 256 * 256
+    for c in bench.CONFIGS.values():
+        lat = bench._Autodecoder(c).init(device="cpu")["params"]
+        assert lat["p_pos"].shape == (1, c["Z"], 2) and lat["a"].shape == (1, c["Z"], c["C"])
