@@ -21,6 +21,10 @@ int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*,
                     int, int, hipStream_t);
 }
 
+size_t enf_xtd_part_bytes(const EnfDims& m, long long P);
+int enf_launch_xtd(const EnfDims& m, void* const* store, long long P, float* const* dpair, float* part, int accumulate,
+                   hipStream_t st);
+
 extern "C" int enf_abi_version(void) { return ENF_ABI_VERSION; }
 
 extern "C" const char* enf_strerror(int code) {
@@ -348,4 +352,54 @@ extern "C" int enf_pair_backward_ex(const EnfDesc* d, const float* x, int64_t x_
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dlt, 0, sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D), st) != hipSuccess) return ENF_ELAUNCH;
   return enf_launch_pair_bwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, lse, dybar, delta, dlt, store, nullptr, nullptr, dx, st);
+}
+
+// ---- weight gradients of the per-pair chain: K3 (STORE) -> K4 (enf_xtd.hip), chunked over signals
+static size_t bw_store_bytes(const EnfDims& m, int cb) {
+  return enf_align((size_t)cb * m.Z * m.N * m.D * (m.bf16 ? 2 : 4));          // one ENF_S_* buffer of a chunk
+}
+static size_t bw_scratch_bytes(const EnfDims& m, int cb) {
+  return (size_t)ENF_NUM_STORE(m.H) * bw_store_bytes(m, cb) + enf_xtd_part_bytes(m, (long long)cb * m.Z * m.N);
+}
+extern "C" size_t enf_backward_weights_scratch_bytes(const EnfDesc* d, int chunk_signals) {
+  if (enf_check_desc(d) != ENF_OK || chunk_signals < 1 || chunk_signals > d->B) return 0;
+  return bw_scratch_bytes(enf_dims(d), chunk_signals);
+}
+
+extern "C" int enf_backward_weights(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                                    const float* lse, const float* dybar, const float* delta, float* dlt,
+                                    float* const* dpair, float* dx, void* scratch, size_t scratch_bytes, void* stream) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (!x || !lt || !packed || !lse || !dybar || !delta || !dlt || !dpair || !scratch) return ENF_EINVAL;
+  for (int i = 0; i < ENF_NUM_PAIR_TENSORS; ++i)
+    if (i != ENF_P_COEFQ && i != ENF_P_COEFV && !dpair[i]) return ENF_EINVAL;
+  EnfDims m = enf_dims(d);
+  const EnfLayout L = enf_layout(m);
+  // the largest chunk of signals whose store fits; with masks, whole groups of mask_signals (signal b replays b % mask_signals)
+  const int step = m.mask_mode == ENF_MASK_READ && m.mask_B < m.B ? m.mask_B : 1;
+  int cb = m.B;
+  while (cb > step && bw_scratch_bytes(m, cb) > scratch_bytes) cb = (cb - 1) / step * step;
+  if (cb < 1 || bw_scratch_bytes(m, cb) > scratch_bytes) return ENF_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int stride = enf_lt_stride(m.H, m.D);
+  if (hipMemsetAsync(dlt, 0, sizeof(float) * (size_t)m.B * m.Z * stride, st) != hipSuccess) return ENF_ELAUNCH;
+  char* sc = (char*)scratch;
+  void* store[ENF_NUM_STORE(4)];
+  const size_t sb = bw_store_bytes(m, cb);
+  for (int i = 0; i < ENF_NUM_STORE(m.H); ++i) store[i] = sc + (size_t)i * sb;
+  float* part = reinterpret_cast<float*>(sc + (size_t)ENF_NUM_STORE(m.H) * sb);
+  const int B = m.B;
+  for (int b0 = 0; b0 < B; b0 += cb) {
+    const int nb = b0 + cb <= B ? cb : B - b0;
+    EnfDims mc = m;
+    mc.B = nb; mc.mask_b0 = b0;
+    const size_t qo = (size_t)b0 * m.N;
+    if ((rc = enf_launch_pair_bwd(mc, L, (const char*)packed, x + (size_t)b0 * x_bstride, x_bstride, lt + (size_t)b0 * m.Z * stride,
+                                  lse + qo * m.H, dybar + qo * m.HD, delta + qo * m.H, dlt + (size_t)b0 * m.Z * stride, store,
+                                  nullptr, nullptr, dx ? dx + qo * m.dx : nullptr, st)))
+      return rc;
+    if ((rc = enf_launch_xtd(mc, store, (long long)nb * m.Z * m.N, dpair, part, b0 > 0, st))) return rc;
+  }
+  return ENF_OK;
 }

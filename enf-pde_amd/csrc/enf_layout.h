@@ -35,6 +35,7 @@ struct EnfDims {
   int OB;      // ceil(O/32) output blocks of the last layer
   // per-call options (EnfDesc): requested pair-kernel variants (ENF_VARIANT_*), relu masks
   int var_fwd, var_bwd, mask_mode, mask_B;
+  int mask_b0;   // signal index of b = 0 in the batch the masks were taken for (set by chunked passes; 0 otherwise)
   unsigned* masks;
 };
 
@@ -92,6 +93,7 @@ inline EnfDims enf_dims(const EnfDesc* d) {
   m.masks = (unsigned*)d->relu_masks;
   m.mask_mode = m.masks ? d->mask_mode : ENF_MASK_OFF;
   m.mask_B = d->mask_signals > 0 ? d->mask_signals : d->B;
+  m.mask_b0 = 0;
   return m;
 }
 

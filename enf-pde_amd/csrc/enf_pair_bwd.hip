@@ -65,6 +65,7 @@ struct PairBwdArgs {
   const char* wzt; const float* wzb;    // ZF only: per (latent, head) [forward | backward] panels of W_zh, and c_zh
   float* dxq;                           // (B, N, dx) or nullptr: gradient w.r.t. the query coordinates, accumulated (atomics)
   const unsigned* masks; int mask_B;    // STORE only: relu masks to linearise at (ENF_MASK_READ), or nullptr
+  int mask_b0;                          // signal index of this launch's b = 0 in the caller's batch (chunked weight-gradient passes)
   int B, N, Z, dx, inv, use_window, nsplit;
 };
 
@@ -458,8 +459,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pQ1, pV1, true, lane, c_bq1);
       if constexpr (STORE) {
         if (A.masks) {        // relu linearised at the masks' point: h1 = a1 where the bit is set (not max(a1, 0))
-          maskq = A.masks[relu_mask_index(b % A.mask_B, A.Z, bzc % A.Z, (A.N + 15) / 16, n0 / 16, 0, lane)];
-          maskv = A.masks[relu_mask_index(b % A.mask_B, A.Z, bzc % A.Z, (A.N + 15) / 16, n0 / 16, 1, lane)];
+          maskq = A.masks[relu_mask_index((b + A.mask_b0) % A.mask_B, A.Z, bzc % A.Z, (A.N + 15) / 16, n0 / 16, 0, lane)];
+          maskv = A.masks[relu_mask_index((b + A.mask_b0) % A.mask_B, A.Z, bzc % A.Z, (A.N + 15) / 16, n0 / 16, 1, lane)];
           relu_apply_mask<NT>(acc, maskq);
         }
       }
@@ -991,7 +992,7 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
                                    void* const* store, const char* wzt, const float* wzb, float* dxq, hipStream_t st) {
   PairBwdArgs A;
   A.dxq = dxq;
-  A.masks = store && m.mask_mode == ENF_MASK_READ ? m.masks : nullptr; A.mask_B = m.mask_B;
+  A.masks = store && m.mask_mode == ENF_MASK_READ ? m.masks : nullptr; A.mask_B = m.mask_B; A.mask_b0 = m.mask_b0;
   const bool zf = !store && wzt && wzb && (size_t)m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
   A.wzt = wzt; A.wzb = wzb; A.inv_d = 1.0f / (float)m.Dt;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.lse = lse; A.dybar = dybar; A.delta = delta;

@@ -47,40 +47,12 @@ SPLIT_K = 4096      # rows per slice of the pair axis: a (D x P)(P x D) product 
                     # library GEMM is run batched over slices of P (split-K) and the slices are summed in fp32
 
 
-def _xt_dot(X, Dl):
-    """X^T @ Dl with fp32 accumulation and fp32 result (X, Dl: (P, D) bf16 or fp32), parallel over the pair axis."""
-    P, D = X.shape
-    nfull = P // SPLIT_K
-    out = None
-    if nfull:
-        Xb = X[:nfull * SPLIT_K].view(nfull, SPLIT_K, D).transpose(1, 2)
-        Db = Dl[:nfull * SPLIT_K].view(nfull, SPLIT_K, D)
-        if X.dtype == torch.float32:
-            out = torch.bmm(Xb, Db).sum(0)
-        else:
-            try:
-                out = torch.bmm(Xb, Db, out_dtype=torch.float32).sum(0)
-            except (TypeError, RuntimeError, NotImplementedError):
-                out = torch.bmm(Xb, Db).float().sum(0)
-    if nfull * SPLIT_K < P:
-        xr, dr = X[nfull * SPLIT_K:], Dl[nfull * SPLIT_K:]
-        if X.dtype == torch.float32:
-            rem = xr.t() @ dr
-        else:
-            try:
-                rem = torch.mm(xr.t(), dr, out_dtype=torch.float32)
-            except (TypeError, RuntimeError, NotImplementedError):
-                rem = (xr.t() @ dr).float()
-        out = rem if out is None else out + rem
-    return out
-
-
 _NO_SPLIT = __import__("os").environ.get("ENF_TRAIN_SPLIT") == "0"      # A/B switch for the split-row reductions below
 
 
 def _col_sum(Dl):
     """Column sums of Dl (P, D) in fp32.  For P >> D the generic reduction kernel runs at a quarter of the memory rate; a
-    batched ones-vector product over the same 4096-row slices as _xt_dot reads Dl at GEMM speed."""
+    batched ones-vector product over 4096-row slices reads Dl at GEMM speed."""
     P, D = Dl.shape
     n = P // SPLIT_K
     if n < 4 or _NO_SPLIT:
@@ -191,61 +163,23 @@ class _PairFunction(torch.autograd.Function):
                                                 _ptr(dybar), _ptr(delta), _ptr(dlt), None, _ptr(dxq), st)
             return (dx_out(), dlt, None) + (None,) * _lib.ENF_NUM_PAIR_TENSORS
 
-        bf16 = model.precision in ("bf16", "bfloat16")
-        sdt = torch.bfloat16 if bf16 else torch.float32
-        ns = _lib.num_store(H)
-        per_b = Z * N * D * ns * (2 if bf16 else 4)
-        cb = max(1, min(B, STORE_BUDGET_BYTES // max(per_b, 1)))
-        if ctx.masks is not None and ctx.masks[1] == "read" and cb < B:      # the masks of signal b are those of b % signals
-            cb = max(ctx.masks[2], cb // ctx.masks[2] * ctx.masks[2])
-        store = torch.empty((ns, cb * Z * N, D), device=dev, dtype=sdt)
+        # weight gradients: ONE library call (include/enf_hip.h: enf_backward_weights) -- K3 writes the layer inputs / deltas
+        # of a chunk of signals into the scratch, K4 (csrc/enf_xtd.hip) forms every X^T delta and bias sum from it
+        desc = model._desc(B, N, Z, masks=ctx.masks) if ctx.masks is not None and ctx.masks[1] == "read" else model._desc(B, N, Z)
+        group = ctx.masks[2] if ctx.masks is not None and ctx.masks[1] == "read" else 1
+        cb = B
+        while cb > group and int(lib.enf_backward_weights_scratch_bytes(ctypes.byref(desc), cb)) > STORE_BUDGET_BYTES:
+            cb = max(group, (cb - 1) // group * group)
+        scratch = torch.empty(int(lib.enf_backward_weights_scratch_bytes(ctypes.byref(desc), cb)), device=dev, dtype=torch.uint8)
         f32 = dict(device=dev, dtype=torch.float32)
-        gAQ1, gAV1, gAF, gAM = (torch.zeros((D, D), **f32) for _ in range(4))
-        gAGB = torch.zeros((D, 2 * HD), **f32)
-        gBQ1, gBV1, gBF, gBM = (torch.zeros(D, **f32) for _ in range(4))
-        gBGB = torch.zeros(2 * HD, **f32)
-        S = _lib
-        for b0 in range(0, B, cb):
-            nb = min(cb, B - b0)
-            if ctx.masks is not None and ctx.masks[1] == "read":
-                if b0 % ctx.masks[2] or (nb % ctx.masks[2] and nb != B):
-                    raise _lib.EnfError("activation-store chunks must hold whole groups of mask_signals signals")
-                desc = model._desc(nb, N, Z, masks=ctx.masks)
-            else:
-                desc = model._desc(nb, N, Z)
-            P = nb * Z * N
-            sl = [store[i, :P] for i in range(ns)]
-            arr = (ctypes.c_void_p * ns)(*[t.data_ptr() for t in sl])
-            xo = xb if ctx.xstride == 0 else xb[b0:]
-            _lib.launch(dev, lib.enf_pair_backward_ex, ctypes.byref(desc), _ptr(xo), ctx.xstride, _ptr(lt[b0 * Z:]), _ptr(blob),
-                                                _ptr(lse[b0:]), _ptr(dybar[b0:]), _ptr(delta[b0:]), _ptr(dlt[b0 * Z:]),
-                                                arr, _ptr(dxq[b0:] if dxq is not None else None), st)
-            gAQ1 += _xt_dot(sl[S.ENF_S_EQ], sl[S.ENF_S_DA1]); gBQ1 += _col_sum(sl[S.ENF_S_DA1])
-            gAV1 += _xt_dot(sl[S.ENF_S_EV], sl[S.ENF_S_DA2]); gBV1 += _col_sum(sl[S.ENF_S_DA2])
-            gAF += _xt_dot(sl[S.ENF_S_G1], sl[S.ENF_S_DA3]); gBF += _col_sum(sl[S.ENF_S_DA3])
-            for h in range(H):
-                V, DA5, DG, DB = (sl[S.ENF_S_HEAD0 + 4 * h + i] for i in range(4))
-                gAM += _xt_dot(V, DA5); gBM += _col_sum(DA5)
-                gAGB[:, h * D:(h + 1) * D] += _xt_dot(sl[S.ENF_S_NH], DG)
-                gAGB[:, HD + h * D:HD + (h + 1) * D] += _xt_dot(sl[S.ENF_S_NH], DB)
-                gBGB[h * D:(h + 1) * D] += _col_sum(DG)
-                gBGB[HD + h * D:HD + (h + 1) * D] += _col_sum(DB)
-        if bf16:
-            # the bf16 store keeps the MFMA fragment order: columns permuted inside every 32-block (include/enf_hip.h,
-            # ENF_S_*); every buffer alike, so the products come out permuted in rows and columns: undo it here
-            c = torch.arange(D, device=dev)
-            j = c % 8
-            true = 32 * (c // 32) + torch.where(j < 4, 4 * ((c % 32) // 8) + j, 16 + 4 * ((c % 32) // 8) + j - 4)
-            inv = torch.empty_like(true)
-            inv[true] = c                                   # stored column of each true feature
-            inv2 = torch.cat([inv + k * D for k in range(2 * H)])
-            gAQ1, gAV1, gAF, gAM = (m[inv][:, inv] for m in (gAQ1, gAV1, gAF, gAM))
-            gAGB = gAGB[inv][:, inv2]
-            gBQ1, gBV1, gBF, gBM = (v[inv] for v in (gBQ1, gBV1, gBF, gBM))
-            gBGB = gBGB[inv2]
+        shapes = [(D, D), (D,), (D, D), (D,), (D, D), (D,), (D, 2 * HD), (2 * HD,), (D, D), (D,)]      # ENF_P_AQ1 .. ENF_P_BM
+        grads = [torch.empty(sh, **f32) for sh in shapes]
+        arr = (ctypes.c_void_p * _lib.ENF_NUM_PAIR_TENSORS)(*([g.data_ptr() for g in grads] + [None, None]))
+        _lib.launch(dev, lib.enf_backward_weights, ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(lt), _ptr(blob), _ptr(lse),
+                    _ptr(dybar), _ptr(delta), _ptr(dlt), arr, _ptr(dxq), _ptr(scratch), scratch.numel(), st)
         assert dlt.shape[1] == stride
         # ENF_P_* order: AQ1,BQ1, AV1,BV1, AF,BF, AGB,BGB, AM,BM, COEFQ,COEFV (frozen: RFF:87-90)
-        return (dx_out(), dlt, None, gAQ1, gBQ1, gAV1, gBV1, gAF, gBF, gAGB, gBGB, gAM, gBM, None, None)
+        return (dx_out(), dlt, None, *grads, None, None)
 
 
 def _ln(x, g, b, n_true):

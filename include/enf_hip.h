@@ -295,6 +295,22 @@ int enf_ode_poly_num_features(int I, int degree);
 int enf_ode_poly_forward(int64_t P, int I, int degree, const float* x, float* feat, void* stream);
 int enf_ode_poly_backward(int64_t P, int I, int degree, const float* x, const float* dfeat, float* dx, void* stream);
 
+/* Weight gradients of the per-pair chain (enf_backward_weights).  enf_pair_backward_ex plus, in the same
+ * call, the gradients of the loss w.r.t. the ten trainable ENF_P_* tensors:
+ *     dpair[ENF_P_A*] = X^T delta  (in, out),   dpair[ENF_P_B*] = 1^T delta      over all B Z N pairs, fp32, OVERWRITTEN
+ * (dpair = host array of ENF_NUM_PAIR_TENSORS device pointers laid out like the tensors enf_pack_pair takes; the two RFF
+ * coefficient entries are ignored: frozen in the reference, rff.py:87-90).  Kernels: K3 in its STORE instantiation writes
+ * every layer's input / delta fragments for a chunk of signals into `scratch` (ENF_S_* above), enf_xtd_kernel reads each of
+ * them ONCE and forms all 3 + 3H products and bias sums on the matrix pipe, a reduction sums slices and chunks in a fixed
+ * order (same inputs -> same bits).  No library GEMM, no host framework op.
+ *   scratch_bytes >= enf_backward_weights_scratch_bytes(d, c) for some chunk size c in 1..B signals: the call uses the
+ *   largest c that fits (with relu masks: a multiple of mask_signals).  c = B: one pass.
+ * EnfDesc.mask_mode = ENF_MASK_READ replays the relu masks as in enf_pair_backward_ex with a store. */
+size_t enf_backward_weights_scratch_bytes(const EnfDesc* d, int chunk_signals);
+int enf_backward_weights(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
+                         const float* lse, const float* dybar, const float* delta, float* dlt, float* const* dpair,
+                         float* dx, void* scratch, size_t scratch_bytes, void* stream);
+
 /* The pair-kernel variant a call with this descriptor runs (ENF_VARIANT_AUTO resolved): ENF_VARIANT_LATENT_SPLIT or
  * ENF_VARIANT_ZFOLD; `backward` = 0 for the forward kernel, 1 for the backward kernel.  Negative ENF_E* on a bad descriptor. */
 int enf_pair_variant(const EnfDesc* d, int backward);

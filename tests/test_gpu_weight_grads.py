@@ -10,6 +10,7 @@ from oracle import enf_ref_np as R
 from oracle import enf_ref_torch as T
 from tests.helpers import make_cfg, make_inputs, build_nef
 from enf_pde_amd.enf.models import TENSOR_PATHS
+from types import SimpleNamespace as NS_
 
 pytestmark = pytest.mark.gpu
 
@@ -96,8 +97,103 @@ def test_weight_grads_chunked_store(cuda, monkeypatch):
     from enf_pde_amd.enf.models import _train
     cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=16, O=1)
     per_b = 8 * 48 * 64 * (7 + 8) * 4
-    monkeypatch.setattr(_train, "STORE_BUDGET_BYTES", 2 * per_b)
+    monkeypatch.setattr(_train, "STORE_BUDGET_BYTES", 2 * per_b + (1 << 20))      # two signals' store + the partial sums
     check(cuda, cfg, B=5, N=48, Z=8, precision="f32", seed=3)
+
+
+def _pair_problem(cuda, D, H, precision, B, N, Z, seed):
+    """Random pair-level inputs of enf_backward_weights / enf_pair_backward: (nef, desc pieces) through the training path's own
+    latent table and effective tensors, so that the activations are in their working range."""
+    import ctypes
+    from enf_pde_amd import _lib
+    from enf_pde_amd.enf.models import _train
+    cfg = make_cfg("rel_pos_periodic", D=D, H=H, C=16, O=1)
+    nef = build_nef(cfg, precision)
+    nef.pair_variants = ("latent_split", "latent_split")
+    prm = R.init_params(seed, cfg, jitter=0.1)
+    params = nef.load_params(prm, device=cuda)
+    x, p, a, s = make_inputs(cfg, B, N, Z, seed + 1)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    W = dict(zip(_train.W_NAMES, nef.param_tensors(params)))
+    desc = nef._desc(B, N, Z)
+    lt = _train.latent_table(nef, W, t(p), t(a), t(s), _train.lt_layout(desc)).contiguous()
+    eff = [e.float().contiguous() for e in _train.effective_pair_params(nef, W)]
+    lib = _lib.load()
+    blob = torch.empty(int(lib.enf_packed_weight_bytes(ctypes.byref(desc))), device=cuda, dtype=torch.uint8)
+    st = ctypes.c_void_p(torch.cuda.current_stream(cuda).cuda_stream)
+    P = lambda v: ctypes.c_void_p(v.data_ptr()) if v is not None else ctypes.c_void_p(0)
+    _lib.check(lib.enf_pack_pair(ctypes.byref(desc), (ctypes.c_void_p * 12)(*[e.data_ptr() for e in eff]), P(blob), st))
+    xs = t(x).contiguous()
+    ybar, lse = torch.empty(B, N, H * D, device=cuda), torch.empty(B, N, H, device=cuda)
+    _lib.check(lib.enf_pair_forward(ctypes.byref(desc), P(xs), N * 2, P(lt), P(blob), P(ybar), P(lse), None, 0, st))
+    g = torch.Generator().manual_seed(seed)
+    dybar = (torch.randn(B, N, H * D, generator=g) / N).to(cuda)
+    delta = (dybar * ybar).view(B, N, H, D).sum(-1).contiguous()
+    return NS_(lib=lib, _lib=_lib, nef=nef, desc=desc, xs=xs, lt=lt, blob=blob, lse=lse, dybar=dybar, delta=delta, st=st, P=P,
+               B=B, N=N, Z=Z, D=D, H=H, bf16=precision == "bf16", keep=(eff, ybar))
+
+
+def _run_backward_weights(q, chunk):
+    import ctypes
+    D, HD = q.D, q.H * q.D
+    shapes = [(D, D), (D,), (D, D), (D,), (D, D), (D,), (D, 2 * HD), (2 * HD,), (D, D), (D,)]
+    grads = [torch.full(sh, float("nan"), device=q.lt.device) for sh in shapes]
+    arr = (ctypes.c_void_p * 12)(*([g.data_ptr() for g in grads] + [None, None]))
+    nbytes = int(q.lib.enf_backward_weights_scratch_bytes(ctypes.byref(q.desc), chunk))
+    assert nbytes > 0
+    scratch = torch.empty(nbytes, device=q.lt.device, dtype=torch.uint8)
+    dlt = torch.empty_like(q.lt)
+    q._lib.check(q.lib.enf_backward_weights(ctypes.byref(q.desc), q.P(q.xs), q.N * 2, q.P(q.lt), q.P(q.blob), q.P(q.lse),
+                                            q.P(q.dybar), q.P(q.delta), q.P(dlt), arr, None, q.P(scratch), nbytes, q.st))
+    torch.cuda.synchronize()
+    return grads, dlt
+
+
+@pytest.mark.parametrize("D,H,precision", [(128, 2, "bf16"), (128, 2, "f32"), (64, 2, "bf16"), (64, 1, "f32"), (128, 1, "bf16"), (64, 4, "bf16")])
+def test_backward_weights_kernel(cuda, D, H, precision):
+    """enf_backward_weights (K3 store + K4) against fp64 X^T delta / column sums of the very activations K3 stores
+    (enf_pair_backward with an explicit store): K4 itself adds nothing but fp32 accumulation order.  Chunked passes give the
+    one-pass result, and the same call twice gives the same bits (fixed reduction order)."""
+    import ctypes
+    B, N, Z = 5, 77, 6                                  # P = 2310 rows: not a multiple of the 32-row tile
+    q = _pair_problem(cuda, D, H, precision, B, N, Z, seed=D + H)
+    ns = 7 + 4 * H
+    sdt = torch.bfloat16 if q.bf16 else torch.float32
+    store = torch.zeros(ns, B * Z * N, D, device=cuda, dtype=sdt)
+    dlt0 = torch.empty_like(q.lt)
+    q._lib.check(q.lib.enf_pair_backward(ctypes.byref(q.desc), q.P(q.xs), N * 2, q.P(q.lt), q.P(q.blob), q.P(q.lse), q.P(q.dybar),
+                                         q.P(q.delta), q.P(dlt0), (ctypes.c_void_p * ns)(*[store[i].data_ptr() for i in range(ns)]), q.st))
+    torch.cuda.synchronize()
+    S = store.double()
+    if q.bf16:                                           # stored column -> true feature (include/enf_hip.h, ENF_S_*)
+        c = torch.arange(D, device=cuda)
+        j = c % 8
+        true = 32 * (c // 32) + torch.where(j < 4, 4 * ((c % 32) // 8) + j, 16 + 4 * ((c % 32) // 8) + j - 4)
+        S = torch.empty_like(S).index_copy_(2, true, S)
+    HD = H * D
+    xtd = lambda i, k: S[i].t() @ S[k]
+    want = [xtd(0, 4), S[4].sum(0), xtd(1, 5), S[5].sum(0), xtd(2, 6), S[6].sum(0),
+            torch.cat([xtd(3, 7 + 4 * h + 2) for h in range(H)] + [xtd(3, 7 + 4 * h + 3) for h in range(H)], 1),
+            torch.cat([S[7 + 4 * h + 2].sum(0) for h in range(H)] + [S[7 + 4 * h + 3].sum(0) for h in range(H)]),
+            sum(xtd(7 + 4 * h, 7 + 4 * h + 1) for h in range(H)), sum(S[7 + 4 * h + 1].sum(0) for h in range(H))]
+    one, dlt1 = _run_backward_weights(q, B)
+    for g, w in zip(one, want):
+        assert torch.isfinite(g).all()
+        assert float((g.double() - w).abs().max()) <= 2e-5 * float(w.abs().max()) + 1e-30
+    assert float((dlt1 - dlt0).abs().max()) <= 2e-5 * float(dlt0.abs().max())
+    again, _ = _run_backward_weights(q, B)
+    assert all(torch.equal(g, h) for g, h in zip(one, again))
+    for chunk in (2, 1):
+        part, dltc = _run_backward_weights(q, chunk)
+        for g, h in zip(part, one):
+            assert float((g - h).abs().max()) <= 2e-5 * float(h.abs().max()) + 1e-30
+        assert float((dltc - dlt0).abs().max()) <= 2e-5 * float(dlt0.abs().max())
+    # too little scratch for even one signal is refused
+    grads = [torch.empty_like(g) for g in one]
+    arr = (ctypes.c_void_p * 12)(*([g.data_ptr() for g in grads] + [None, None]))
+    small = torch.empty(1024, device=cuda, dtype=torch.uint8)
+    assert q.lib.enf_backward_weights(ctypes.byref(q.desc), q.P(q.xs), N * 2, q.P(q.lt), q.P(q.blob), q.P(q.lse), q.P(q.dybar),
+                                      q.P(q.delta), q.P(dlt0), arr, None, q.P(small), 1024, q.st) == -4
 
 
 def test_training_path_matches_inference_path(cuda):
