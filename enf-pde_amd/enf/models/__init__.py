@@ -187,6 +187,17 @@ class EquivariantCrossAttentionNeF:
                                                 # keys); None = the class default below (tests flip it to cover both kernels)
         self._masks = None                      # (buffer, "write" | "read", signals) inside relu_masks(), else None
 
+    def with_precision(self, precision):
+        """The same model (fields, invariants) running its per-pair contractions in another arithmetic ("f32" | "bf16"), with
+        caches of its own; parameters are plain tensors, so both models take the same parameter tree."""
+        import copy
+        if precision not in _lib.PREC:
+            raise ValueError(f"unknown precision {precision!r}")
+        m = copy.copy(self)
+        m.precision = precision
+        m._pack_cache, m._ws_cache, m._ws_gen, m._ws_tags, m._masks = {}, {}, 0, {}, None
+        return m
+
     # ------------------------------------------------------------------ descriptors / buffers
     def _desc(self, B, N, Z, masks=None):
         """The call descriptor; ``masks`` = a (buffer, mode, signals) triple for calls whose pair kernels take relu masks."""

@@ -31,7 +31,13 @@ class NonMetaTrainState:
 class NonMetaPDETrainer:
     """``config`` fields used: optimizer.learning_rate_enf, optimizer.learning_rate_codes,
     training.max_num_sampled_points.  ``autodecoder``: enf_pde_amd.enf.latents.autodecoder.PositionOrientationFeatureAutodecoder
-    sized for the training set.  The latent-ODE phase is outside this build's scope."""
+    sized for the training set.
+
+    Scope: SURVEY.md 8f row 1 asks for the nef phase (the first-order decoder gradients this build accelerates).  The
+    reference's other two steps of this trainer -- ``_ode_train_step`` (:173-199, clip + adamw on the latent ODE over the
+    auto-decoder's latents) and ``_val_step`` (:201-241, fit validation latents from scratch, then roll out) -- are beyond
+    section 8; they exist here as methods that raise, so that a config which schedules them fails loudly instead of
+    silently training less than the reference does.  The MAML trainer (pde_trainer.py) has both phases."""
 
     def __init__(self, config, nef, autodecoder, coords, seed=42):
         self.config, self.nef, self.autodecoder, self.coords, self.seed = config, nef, autodecoder, coords, seed
@@ -47,6 +53,18 @@ class NonMetaPDETrainer:
         return NonMetaTrainState(params={"nef": nef_params, "autodecoder": ad},
                                  nef_opt_state=self.nef_opt.init(self.nef.param_tensors(nef_params)),
                                  autodecoder_opt_state=self.autodecoder_opt.init(list(ad["params"].values())), step=0, rng=g)
+
+    def save_checkpoint(self, state, path, epoch=0):
+        """_base_pde_trainer.py:192-202: the whole train state (parameters, every optimiser's count / mu / nu, step, rng)
+        and the config, in one .npz (enf_pde_amd/checkpoint.py: save_train_state)."""
+        from ...checkpoint import save_train_state
+        save_train_state(path, state, config=self.config, epoch=epoch)
+
+    def load_checkpoint(self, path, **init_kwargs):
+        """_base_pde_trainer.py:204-237: restore into a freshly initialised state of this trainer.  Returns (state, epoch)."""
+        from ...checkpoint import load_train_state
+        state, epoch, _ = load_train_state(path, self.init_train_state(**init_kwargs))
+        return state, epoch
 
     def loss_and_grads(self, state, initial_state, traj_idx, mask=None):
         """(recon_loss, grads['nef'] as 46 tensors, grads['autodecoder'] as dense tensors like the latent table)."""
@@ -97,3 +115,11 @@ class NonMetaPDETrainer:
     def nef_train_step_autodec_only(self, state, batch, mask=None):
         """Only the latents move (:139-171)."""
         return self._step(state, batch, mask, False)
+
+    def ode_train_step(self, state, batch):
+        raise NotImplementedError("NonMetaPDETrainer: the latent-ODE phase of nonmaml_pde_trainer.py:173-199 is outside "
+                                  "SURVEY.md section 8; use MetaSGDPDETrainer.ode_train_step for the latent ODE")
+
+    def val_step(self, state, batch):
+        raise NotImplementedError("NonMetaPDETrainer: the validation roll-out of nonmaml_pde_trainer.py:201-241 is outside "
+                                  "SURVEY.md section 8; use MetaSGDPDETrainer.val_step")

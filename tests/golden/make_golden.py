@@ -89,6 +89,41 @@ def make_inner_loop():
     return rec
 
 
+def make_config1_trace():
+    """BASELINE.json config 1 at FULL size (32 x 32 grid, 16 latents, D = 64, H = 2, C = 16, ponita, N_s = 1024,
+    3 inner SGD steps, B = 8; hparams config_diff_plane.yaml:39-55,92-96): the inner-loop trace and the decode of the fitted
+    latents on the full grid, fp64 oracle."""
+    cfg = make_cfg(invariant="ponita", D=64, H=2, C=16, O=1, freq=(0.05, 0.01))
+    prm = R.init_params(41, cfg, jitter=0.05)
+    B, Z, S, g = 8, 16, 3, 32
+    lin = np.linspace(-1, 1, g)
+    coords = np.stack(np.meshgrid(lin, lin), -1).reshape(-1, 2)
+    rng = np.random.default_rng(42)
+    ks = np.stack(np.meshgrid(np.arange(-4, 5), np.arange(-4, 5), indexing="ij"), -1).reshape(-1, 2)
+    img = (rng.standard_normal((B, 1, len(ks))) * np.cos(np.pi * coords @ ks.T + rng.uniform(0, 2 * np.pi, (B, 1, len(ks))))).sum(-1)
+    img = (img / img.std(1, keepdims=True))[..., None]                    # band-limited, unit variance (SURVEY.md 8d)
+    masks = np.stack([rng.permutation(g * g) for _ in range(S + 1)], 1)     # N_s = N: every step sees a permutation of the grid
+    lat = R.init_latents(1, Z, 16, "ponita")
+    lrs = {"p_pos": np.array([1.0]), "p_ori": np.array([1.0]), "a": np.full(16, 5.0), "gaussian_window": np.array([0.0])}
+    t64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
+    tp = T.to_torch(prm, torch.float64)
+    loss, fitted = T.inner_loop(tp, cfg, {k: t64(v) for k, v in lat.items()}, {k: t64(v) for k, v in lrs.items()}, t64(coords),
+                                t64(img), torch.tensor(masks))
+    fit = {k: v.detach() for k, v in fitted.items()}
+    with torch.no_grad():
+        recon = T.nef_apply(tp, cfg, t64(coords)[None].expand(B, -1, -1), torch.cat([fit["p_pos"], fit["p_ori"]], -1), fit["a"],
+                            fit["gaussian_window"])
+    rec = dict(coords=coords, img=img, masks=masks, loss=np.float64(loss.item()), recon=recon.numpy(), param_seed=np.int64(41),
+               jitter=np.float64(0.05))
+    for k, v in lat.items():
+        rec["lat0/" + k] = v
+    for k, v in lrs.items():
+        rec["lr/" + k] = v
+    for k, v in fit.items():
+        rec["fit/" + k] = v.numpy()
+    return rec
+
+
 # latent-ODE fixtures: name -> (ode cfg kwargs, B, Z, latent_dim, param seed)
 ODE_CASES = {
     "ode_rel_pos_periodic": (dict(invariant="rel_pos_periodic", num_hidden=32, basis_dim=16, num_layers=2), 2, 6, 8, 31),
@@ -132,3 +167,5 @@ if __name__ == "__main__":
         print(name, {k: v.shape for k, v in rec.items() if hasattr(v, "shape") and not k.startswith("W/")})
     np.savez_compressed(os.path.join(HERE, "inner_loop_ponita.npz"), **make_inner_loop())
     print("inner_loop_ponita written")
+    np.savez_compressed(os.path.join(HERE, "config1_trace.npz"), **make_config1_trace())
+    print("config1_trace written")

@@ -132,3 +132,34 @@ def test_loud_failure_modes(cuda):
         nef.apply(params, t(1, 8, 2), t(1, 4, 2), t(1, 4, 8), None)                 # window requested, no sigma
     with pytest.raises(_lib.EnfError):
         nef.apply(params, t(1, 8, 2).cpu(), t(1, 4, 2), t(1, 4, 8), t(1, 4, 1) + 1)  # host tensor
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_config1_full_size_trace(cuda, precision):
+    """BASELINE.json config 1 at full size (32 x 32, 16 latents, 3 inner SGD steps, B = 8; tests/golden/config1_trace.npz):
+    the HIP inner loop reproduces the oracle's fitted latents and final loss, and the decode of those latents on the full
+    grid reproduces the oracle's field (field MSE <= 1e-5, BASELINE.json)."""
+    from enf_pde_amd.fitting import inner_loop, decode
+    g = np.load(os.path.join(GOLD, "config1_trace.npz"))
+    cfg = make_cfg(invariant="ponita", D=64, H=2, C=16, O=1, freq=(0.05, 0.01))
+    prm = R.init_params(int(g["param_seed"]), cfg, jitter=float(g["jitter"]))
+    nef = build_nef(cfg, precision)
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(np.asarray(v), dtype=torch.float32, device=cuda)
+    lat0 = {k[5:]: t(g[k]) for k in g.files if k.startswith("lat0/")}
+    lrs = {k[3:]: t(g[k]) for k in g.files if k.startswith("lr/")}
+    loss, fit = inner_loop(nef, params, lat0, lrs, t(g["coords"]), t(g["img"]), torch.tensor(g["masks"], device=cuda))
+    tol = 5e-4 if precision == "f32" else 5e-2
+    assert abs(loss.item() - float(g["loss"])) < tol * max(1.0, float(g["loss"]))
+    for k, v in fit.items():
+        ref = g["fit/" + k]
+        init = np.repeat(g["lat0/" + k], ref.shape[0], 0)
+        if np.abs(ref - init).max() == 0:
+            assert np.abs(v.cpu().numpy() - ref).max() == 0, k
+        else:
+            assert _rel(v.cpu().numpy() - init, ref - init) < tol * 20, k
+    # decode of the ORACLE's fitted latents (so that the comparison is of the decoder alone)
+    pose = t(np.concatenate([g["fit/p_pos"], g["fit/p_ori"]], -1))
+    field = decode(nef, params, t(g["coords"]), pose, t(g["fit/a"]), t(g["fit/gaussian_window"])).cpu().numpy()
+    assert field.shape == g["recon"].shape
+    assert ((field - g["recon"]) ** 2).mean() < (1e-10 if precision == "f32" else 1e-5)

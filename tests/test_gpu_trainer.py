@@ -200,3 +200,45 @@ def test_nonmeta_train_step(cuda):
     for _ in range(10):
         l, new = tr.nef_train_step(new, batch)
     assert float(l) < l0
+
+
+def test_checkpoint_round_trip_resumes_training(cuda, tmp_path):
+    """_base_pde_trainer.py:192-237: N steps, save, load into a fresh trainer, M steps == N + M steps, bit for bit -- the
+    checkpoint carries parameters, every optimiser's count / mu / nu, the step and the mask generator's state."""
+    cfg, prm, coords, img, lat0, lrs, masks = _problem(seed=3)
+    conf = NS(optimizer=NS(learning_rate_enf=1e-3, learning_rate_codes=1e-3), meta=NS(learning_rate_meta_sgd=1e-2,
+              num_inner_steps=2, inner_learning_rate_p=0.5, inner_learning_rate_a=2.0, inner_learning_rate_window=0.0,
+              noise_pos_inner_loop=0.0), nef=NS(optimize_gaussian_window=False), training=NS(max_num_sampled_points=32))
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    batch = t(img).reshape(3, 8, 8, 1)
+
+    def trainer():
+        nef = build_nef(cfg, "f32")
+        ad = PositionOrientationFeatureAutodecoderMeta(1, 9, 8, 2, 0, gaussian_window_size=-1)
+        tr = MetaSGDPDETrainer(conf, nef, ad, t(coords), seed=0, second_order="fd")
+        return tr, nef
+
+    tr, nef = trainer()
+    state = tr.init_train_state(nef.load_params(prm, device=cuda))
+    for _ in range(3):                                        # masks drawn from state.rng: the generator state matters
+        _, state = tr.nef_train_step(state, batch)
+    path = str(tmp_path / "ckpt.npz")
+    tr.save_checkpoint(state, path, epoch=7)
+    ref = state
+    for _ in range(2):
+        lref, ref = tr.nef_train_step(ref, batch)
+    tr2, nef2 = trainer()
+    loaded, epoch = tr2.load_checkpoint(path)
+    assert epoch == 7 and loaded.step == 3 and loaded.nef_opt_state["count"] == 3
+    assert isinstance(loaded.nef_opt_state["count"], int)
+    for a, b in zip(nef.param_tensors(state.params["nef"]), nef2.param_tensors(loaded.params["nef"])):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    for _ in range(2):
+        l2, loaded = tr2.nef_train_step(loaded, batch)
+    assert float(l2) == float(lref)
+    for a, b in zip(nef.param_tensors(ref.params["nef"]), nef2.param_tensors(loaded.params["nef"])):
+        assert torch.equal(a, b)
+    for k in ref.params["meta_sgd_lrs"]:
+        assert torch.equal(ref.params["meta_sgd_lrs"][k], loaded.params["meta_sgd_lrs"][k])
+    for part in ("mu", "nu"):
+        assert all(torch.equal(a, b) for a, b in zip(ref.nef_opt_state[part], loaded.nef_opt_state[part]))

@@ -358,3 +358,41 @@ def test_bench_configs_cover_baseline_json():
     for c in bench.CONFIGS.values():
         lat = bench._Autodecoder(c).init(device="cpu")["params"]
         assert lat["p_pos"].shape == (1, c["Z"], 2) and lat["a"].shape == (1, c["Z"], c["C"])
+
+
+def test_train_state_checkpoint_keeps_dtypes_and_rng(tmp_path):
+    """checkpoint.save_train_state / load_train_state on a hand-made state (CPU): integer counters stay integers, tensors keep
+    their dtype, the generator resumes its sequence, a mismatching template is refused."""
+    from enf_pde_amd import checkpoint as ck
+    from enf_pde_amd.fitting.trainers.pde_trainer import TrainState
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    params = {"nef": {"params": {"w": mk(3, 4), "b": mk(4)}}, "meta_sgd_lrs": {"a": mk(8)},
+              "autodecoder": {"params": {"a": mk(1, 5, 8)}}}
+    opt = lambda ts: {"count": 11, "mu": [mk(*t.shape) for t in ts], "nu": [mk(*t.shape).abs() for t in ts]}
+    st = TrainState(params=params, nef_opt_state=opt([params["nef"]["params"]["b"], params["nef"]["params"]["w"]]),
+                    autodecoder_opt_state=opt([params["autodecoder"]["params"]["a"]]), meta_sgd_opt_state=opt([params["meta_sgd_lrs"]["a"]]),
+                    ode_opt_state=None, step=11, rng=g)
+    path = str(tmp_path / "state.npz")
+    ck.save_train_state(path, st, config=NS(meta=NS(num_inner_steps=3), name="x"), epoch=4)
+    nxt = torch.randn(6, generator=g)                                   # what the generator yields after the save point
+    zero = lambda ts: {"count": 0, "mu": [torch.zeros_like(t) for t in ts], "nu": [torch.zeros_like(t) for t in ts]}
+    tmpl = TrainState(params={k: ck.unflatten_tree({n: torch.zeros_like(v) for n, v in ck.flatten_tree(params[k]).items()}) for k in params},
+                      nef_opt_state=zero(st.nef_opt_state["mu"]), autodecoder_opt_state=zero(st.autodecoder_opt_state["mu"]),
+                      meta_sgd_opt_state=zero(st.meta_sgd_opt_state["mu"]), ode_opt_state=None)
+    new, epoch, conf = ck.load_train_state(path, tmpl)
+    assert epoch == 4 and new.step == 11 and conf == {"meta": {"num_inner_steps": 3}, "name": "x"}
+    assert type(new.nef_opt_state["count"]) is int and new.nef_opt_state["count"] == 11
+    for k, v in ck.flatten_tree(params).items():
+        assert torch.equal(ck.flatten_tree(new.params)[k], v)
+    assert all(torch.equal(a, b) for a, b in zip(new.meta_sgd_opt_state["nu"], st.meta_sgd_opt_state["nu"]))
+    assert torch.equal(torch.randn(6, generator=new.rng), nxt)
+    with np.load(path) as z:
+        assert z["nef_opt_state/count"].dtype == np.int64 and z["rng_state"].dtype == np.uint8
+    tmpl.params["nef"]["params"]["extra"] = torch.zeros(1)
+    with pytest.raises(ValueError):
+        ck.load_train_state(path, tmpl)
+    # load_tree no longer casts integer entries to float
+    ck.save_tree(str(tmp_path / "t.npz"), {"count": torch.tensor(7), "w": torch.ones(2, dtype=torch.float64)})
+    tr = ck.load_tree(str(tmp_path / "t.npz"))
+    assert tr["count"].dtype == torch.int64 and tr["w"].dtype == torch.float32

@@ -216,4 +216,23 @@ def test_oracle_reproduces_golden(name):
 def test_golden_files_are_all_covered():
     from tests.golden.make_golden import ODE_CASES
     files = {os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLD, "*.npz"))}
-    assert files == set(CASES) | set(ODE_CASES) | {"inner_loop_ponita"}
+    assert files == set(CASES) | set(ODE_CASES) | {"inner_loop_ponita", "config1_trace"}
+
+
+def test_config1_full_size_trace_is_reproduced_by_the_numpy_oracle():
+    """tests/golden/config1_trace.npz (BASELINE.json config 1 at full size, written by the torch restatement): the
+    INDEPENDENT numpy restatement decodes the fitted latents to the same field, the stored loss is the loss of that field on
+    the last mask, and the inner loop moved the latents (a, poses) but not the frozen window."""
+    g = np.load(os.path.join(GOLD, "config1_trace.npz"))
+    cfg = make_cfg(invariant="ponita", D=64, H=2, C=16, O=1, freq=(0.05, 0.01))
+    prm = R.init_params(int(g["param_seed"]), cfg, jitter=float(g["jitter"]))
+    B, N = g["img"].shape[:2]
+    assert (B, N, g["fit/a"].shape[1], g["masks"].shape) == (8, 32 * 32, 16, (1024, 4))
+    pose = np.concatenate([g["fit/p_pos"], g["fit/p_ori"]], -1)
+    half = slice(0, 4)                                         # half the batch keeps the (B, N, Z, .) intermediates small
+    out = R.nef_apply(prm, cfg, np.repeat(g["coords"][None], 4, 0), pose[half], g["fit/a"][half], g["fit/gaussian_window"][half])
+    assert np.abs(out - g["recon"][half]).max() < 1e-9
+    last = g["masks"][:, -1]
+    assert abs(((g["recon"][:, last] - g["img"][:, last]) ** 2).mean() - float(g["loss"])) < 1e-12
+    assert np.abs(g["fit/a"] - g["lat0/a"]).max() > 1e-3 and np.abs(g["fit/p_pos"] - g["lat0/p_pos"]).max() > 1e-5
+    assert np.all(g["fit/gaussian_window"] == g["lat0/gaussian_window"])
