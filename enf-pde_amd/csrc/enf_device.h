@@ -284,6 +284,16 @@ DEV void gelu_fg2(f32x2 x, f32x2& g, f32x2& dg) {
   g = x * s;
   dg = g * (1.0f - s) * (x2 * (6.0f * c * 0.044715f) + 2.0f * c) + s;
 }
+// the same one value at a time (no register-pair constraints for the allocator: the packed form spills in K3)
+DEV void gelu_fg1(float x, float& g, float& dg) {
+  const float c = 0.7978845608028654f;
+  const float c2 = -2.0f * c * 1.4426950408889634f;
+  const float x2 = x * x;
+  const float u = x * (c2 + (c2 * 0.044715f) * x2);
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+  g = x * s;
+  dg = fmaf(g - g * s, fmaf(x2, 6.0f * c * 0.044715f, 2.0f * c), s);
+}
 // in place: X <- gelu(X), returns gelu'(X) in G
 template <int NT> DEV void gelu_fg_tiles(f32x4 (&X)[NT], f32x4 (&G)[NT]) {
 #pragma unroll
@@ -361,6 +371,14 @@ DEV void stage_issue_p(const Pipe& P, unsigned src_off, char* dst, int lane) {
 DEV void stage_open(const Pipe& P) { if (P.early) { stage_wait(); __syncthreads(); } }
 DEV void stage_close(Pipe& P) { if (!P.early) { stage_wait(); __syncthreads(); } P.cur ^= 1; }
 DEV void pipe_finish(const Pipe& P) { if (P.early) { stage_wait(); __syncthreads(); } }
+// look-ahead staging: retire this stage (its successor has landed, every wave is done with this slot), then refill this slot
+template <int NEXT_BYTES, int NW>
+DEV void stage_close_la(Pipe& P, char* ring, unsigned next, int lane) {
+  stage_wait();
+  __syncthreads();
+  if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + P.cur * STAGE_MAX, lane);
+  P.cur ^= 1;
+}
 
 template <int KBIN, int MTOUT, bool BF16> struct PanelCfg {
   static constexpr int MT_BYTES = KBIN * (BF16 ? 1024 : 2048);
@@ -376,14 +394,23 @@ template <int KBIN, int MTOUT, bool BF16> struct PanelCfg {
 // `next`, NEXT_BYTES long; NO_STAGE = nothing follows) streams into the other ring slot; one
 // wait + one barrier per stage publish it.  `panel` / `next` are blob byte offsets (wave-uniform).
 // `active` (wave-uniform) lets a wave without work keep the staging / barrier cadence.
-template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES, int INIT = INIT_ACC>
+//
+// LA ("look-ahead over the epilogue", single-stage panels only): the kernel keeps ONE stage in flight at all times instead
+// of issuing it at the start of the stage before.  Precondition: this panel is resident and visible in ring[cur] AND the
+// stage after it is already streaming into the other slot; `next` names the stage AFTER THAT, issued into this stage's own
+// slot right behind the barrier that retires it -- so it streams under the vector-ALU epilogue that follows this call and
+// under the next stage's MFMAs, not under those MFMAs alone (a D x D stage is ~1000 cycles of MFMAs for the two waves of a
+// SIMD, the DMA of its successor ~3000: without this every stage that follows an epilogue waits for its panel).
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES, int INIT = INIT_ACC, bool LA = false>
 DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned next,
                     bool active, int lane, const float* bias = nullptr) {
   using C = PanelCfg<KBIN, MTOUT, BF16>;
+  static_assert(!LA || C::SPP == 1, "look-ahead staging: single-stage panels");
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
     stage_open(P);
-    if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
+    if constexpr (LA) {}
+    else if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     if (active) gemm_stage<BF16, KBIN, C::MTS, INIT>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane, bias + 16 * sp * C::MTS);
     else if constexpr (INIT != INIT_ACC) {        // a wave that only keeps the barrier cadence still gets defined values
@@ -392,20 +419,23 @@ DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, ch
         acc[sp * C::MTS + mt] = INIT == INIT_BIAS ? *reinterpret_cast<const f32x4*>(bias + 16 * (sp * C::MTS + mt) + 4 * (lane >> 4))
                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    stage_close(P);
+    if constexpr (LA) stage_close_la<NEXT_BYTES, NW>(P, ring, next, lane);
+    else stage_close(P);
   }
 }
 
 // panel_gemm that additionally hands every out-tile's FLIPPED product to `flip(tile, acc)`
 // (acc starts at flip_init(tile)); TRANS = false skips the transposed product.
-template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW, bool TRANS, int INIT = INIT_ACC, typename InitFn, typename FlipFn>
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW, bool TRANS, int INIT = INIT_ACC, bool LA = false, typename InitFn, typename FlipFn>
 DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel,
                          unsigned next, int lane, InitFn&& flip_init, FlipFn&& flip, const float* bias = nullptr) {
   using C = PanelCfg<KBIN, MTOUT, BF16>;
+  static_assert(!LA || C::SPP == 1, "look-ahead staging: single-stage panels");
 #pragma unroll
   for (int sp = 0; sp < C::SPP; ++sp) {
     stage_open(P);
-    if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
+    if constexpr (LA) {}
+    else if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
     const char* slot = ring + P.cur * STAGE_MAX;
     if constexpr (TRANS && BF16 && ENF_ASM_GEMM && GemmStageAsm<KBIN, C::MTS, ENF_ASM_LITE != 0>::available) {
@@ -444,7 +474,8 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
         flip(sp * C::MTS + mt, af);
       }
     }
-    stage_close(P);
+    if constexpr (LA) stage_close_la<NEXT_BYTES, NW>(P, ring, next, lane);
+    else stage_close(P);
   }
 }
 

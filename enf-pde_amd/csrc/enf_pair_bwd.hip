@@ -51,6 +51,15 @@
 #ifndef ENF_K3_FUSED_GELU
 #define ENF_K3_FUSED_GELU 0
 #endif
+#ifndef ENF_K3_ZF_FUSED       // z-fold heads: gelu(a5) and gelu'(a5) from one exp + rcp (a5 is overwritten by its gelu')
+#define ENF_K3_ZF_FUSED 1
+#endif
+#ifndef ENF_K3_DY2            // z-fold heads: read d ybar twice instead of keeping it in 32 registers across the head's vector phase
+#define ENF_K3_DY2 0
+#endif
+#ifndef ENF_K3_LA             // z-fold bf16: look-ahead staging (enf_device.h: panel_gemm<.., LA>) -- one stage always in flight
+#define ENF_K3_LA 1
+#endif
 #ifndef ENF_K3_LDSACC
 #define ENF_K3_LDSACC 1
 #endif
@@ -314,6 +323,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   using GG = PanelCfg<2 * KB, NT, BF16>;              // one head's d n^ += AGB_h [dgamma; dbeta]
   constexpr int ST_GG = GG::STAGE, PANEL_GG = GG::BYTES;
   constexpr int NW = NWAVES;
+  // look-ahead staging: every panel of the z-fold bf16 chain is ONE 32 KB (8 KB at D = 64) stage, so the stage after next
+  // can be issued behind each stage's closing barrier; call sites pass `LA ? <stage after next> : <next stage>`
+  constexpr bool LA = ZF && BF16 && ENF_K3_LA != 0 && Cfg::DD::SPP == 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem + SM::RING;
   float* cst = reinterpret_cast<float*>(smem + SM::CONSTS);
@@ -391,6 +403,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   else P.rs2 = P.rs;
   const unsigned pWG = (unsigned)A.L.awg;
   first_stage<ST_DD>(P, ring, pQ1, wave, lane);
+  if constexpr (LA) stage_issue_p<ST_DD, NW>(P, pV1, ring + STAGE_MAX, lane);       // the second stage is in flight from here on
 
   // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature
   // 16 t + col, summed over the queries n = 4 quad + i of every tile (flipped products).
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acq, lane, quad, phq);
       make_frags<BF16, KB>(F, acc);
-      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pQ1, pV1, true, lane, c_bq1);
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(acc, F, P, ring, pQ1, LA ? pF : pV1, true, lane, c_bq1);
       if constexpr (STORE) {
         if (A.masks) {        // relu linearised at the masks' point: h1 = a1 where the bit is set (not max(a1, 0))
           maskq = A.masks[relu_mask_index((b + A.mask_b0) % A.mask_B, A.Z, bzc % A.Z, (A.N + 15) / 16, n0 / 16, 0, lane)];
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad, phv);
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EV], srow, D, F, quad);
-      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(acc, F, P, ring, pV1, pF, true, lane, c_bv1);
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(acc, F, P, ring, pV1, LA ? STAGE_RS2 : pF, true, lane, c_bv1);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       if (STORE && A.masks) relu_mask = maskv;
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
-      if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, STAGE_RS2, true, lane, c_bf);
+      if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a3, F, P, ring, pF, LA ? STAGE_RS2 | (unsigned)PANEL_DD : STAGE_RS2, true, lane, c_bf);
       else panel_gemm<KB, NT, BF16, ST_GB, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, pGB, true, lane, c_bf);
 #if ENF_K3_FUSED_GELU
 #pragma unroll
@@ -547,61 +560,106 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         const unsigned wzf = STAGE_RS2 | (unsigned)(h * 2 * PANEL_DD), wzb = wzf + PANEL_DD;
         // ---- a5 = W_zh^T n + c_zh
         f32x4 a5[NT], v[NT];
-        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a5, F, P, ring, wzf, wzb, true, lane, zv + H * D + h * D);
+        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a5, F, P, ring, wzf, LA ? gM : wzb, true, lane, zv + H * D + h * D);
         BSTAMP(4 + 6 * h);
         float mu2, r2;
+#if ENF_K3_ZF_FUSED
+        K3_SCHED_FENCE();
+        // gelu(a5) and gelu'(a5) share their sigmoid, and nothing but reductions sits between their uses in this branch:
+        // one exp + rcp per element, a5 <- gelu'(a5) in place (the same 32 registers it was kept alive in anyway)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float g, d;
+            gelu_fg1(a5[t][i], g, d);
+            v[t][i] = g;
+            a5[t][i] = d;
+          }
+          asm volatile("" : "+v"(v[t]), "+v"(a5[t]));
+          K3_SCHED_FENCE();
+        }
+#else
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[t][i] = gelu_f(a5[t][i]);
         }
+#endif
         ln_stats<NT>(v, mu2, r2, A.inv_d);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[t][i] = (v[t][i] - mu2) * r2;
-        f32x4 dy[NT];
-        {
-          const float* dyrow = A.dybar + qrow * (H * D) + h * D;
+#if ENF_K3_DY2
+        // d ybar_h is read twice (a dot product now, the delta below) instead of living in 32 registers in between
+        const float* dyrow = A.dybar + qrow * (H * D) + h * D + 4 * quad;
+        float s0 = 0.f, sd = 0.f;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t + 4 * quad);
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(dyrow + 16 * t);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { s0 = fmaf(d[i], v[t][i], s0); sd += d[i]; }
         }
-        float s0 = 0.f;
+#else
+        f32x4 dy[NT];
+        float s0 = 0.f, sd = 0.f;
+        {
+          const float* dyrow = A.dybar + qrow * (H * D) + h * D + 4 * quad;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s0 = fmaf(dy[t][i], v[t][i], s0);
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0 = fmaf(dy[t][i], v[t][i], s0); sd += dy[t][i]; }
+        }
+#endif
         const float datt = xquad_sum(s0);
         dlogit[h] = nvalid ? att[h] * (datt - A.delta[qrow * H + h]) : 0.f;
         const float ah = nvalid ? att[h] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        // LayerNorm backward of the weighted cotangent ah * dy: its two means follow from the sums above,
+        // mean(ah dy) = ah mean(dy),  mean(ah dy v) = ah datt / D
+        const float m1 = ah * xquad_sum(sd) * A.inv_d, m2 = ah * datt * A.inv_d;
+#if ENF_K3_DY2
+        f32x4 dy[NT];
+        {
+          const float* dyrow2 = dyrow;
+          asm volatile("" : "+v"(dyrow2));          // a second read, not a value kept alive
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT; ++t) {
+            K3_OPAQUE(a5[t]);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dyrow2 + 16 * t);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { dy[t][i] *= ah; s1 += dy[t][i]; s2 = fmaf(dy[t][i], v[t][i], s2); }
-        const float m1 = xquad_sum(s1) * A.inv_d, m2 = xquad_sum(s2) * A.inv_d;
+            for (int i = 0; i < 4; ++i)
+              dy[t][i] = r2 * (fmaf(ah, d[i], -m1) - v[t][i] * m2) * (ENF_K3_ZF_FUSED ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
+          }
+        }
+#else
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           K3_OPAQUE(a5[t]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * gelu_grad_f(a5[t][i]);   // d a5
+          for (int i = 0; i < 4; ++i)
+            dy[t][i] = r2 * (fmaf(ah, dy[t][i], -m1) - v[t][i] * m2) * (ENF_K3_ZF_FUSED ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
         }
+#endif
         BSTAMP(5 + 6 * h);
         Frags<BF16, KB> FA;
         make_frags<BF16, KB>(FA, dy);
         // ---- d n += W_zh d a5
-        panel_gemm<KB, NT, BF16, ST_DD>(dnh, FA, P, ring, wzb, gM, true, lane);
+        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ACC, LA>(dnh, FA, P, ring, wzb, LA ? pWG + h * PANEL_DD : gM, true, lane);
         // ---- d v0 += sum_n dv (1 + gamma), both as flipped products (rows = queries)
         f32x4 dvf[NT];
         {
           f32x4 none[1];
-          panel_gemm_flip<KB, NT, BF16, ST_DD, NW, false, INIT_ZERO>(
-              none, FA, P, ring, gM, pWG + h * PANEL_DD, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
+          const unsigned nxt = h + 1 < H ? wzf + 2 * PANEL_DD : gF;          // the stage after this head's last one ...
+          const unsigned nxt2 = h + 1 < H ? wzb + 2 * PANEL_DD : gV1;        // ... and the one after that
+          panel_gemm_flip<KB, NT, BF16, ST_DD, NW, false, INIT_ZERO, LA>(
+              none, FA, P, ring, gM, LA ? nxt : pWG + h * PANEL_DD, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
               [&](int mt, const f32x4& af) { dvf[mt] = af; });
           float part[NT];
-          const unsigned nxt = h + 1 < H ? wzf + 2 * PANEL_DD : gF;
-          panel_gemm_flip<KB, NT, BF16, ST_DD, NW, false>(
-              none, F, P, ring, pWG + h * PANEL_DD, nxt, lane,
+          panel_gemm_flip<KB, NT, BF16, ST_DD, NW, false, INIT_ACC, LA>(
+              none, F, P, ring, pWG + h * PANEL_DD, LA ? nxt2 : nxt, lane,
               [&](int mt) { const float bc = c_bgb[h * D + 16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
               [&](int mt, const f32x4& af) {
                 part[mt] = af[0] * dvf[mt][0] + af[1] * dvf[mt][1] + af[2] * dvf[mt][2] + af[3] * dvf[mt][3];
@@ -798,14 +856,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       make_frags<BF16, KB>(F, dnh);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA3], srow, D, F, quad);
       f32x4 acc[NT];
-      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO>(acc, F, P, ring, gF, gV1, true, lane);                  // d g1
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(acc, F, P, ring, gF, LA ? pQ1 : gV1, true, lane);       // d g1
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = ((relu_mask >> (4 * t + i)) & 1u) ? acc[t][i] : 0.f;             // d a2
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA2], srow, D, F, quad);
-      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO>(acc, F, P, ring, gV1, pQ1, true, lane);                 // d E_v
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(acc, F, P, ring, gV1, LA ? gQ1 : pQ1, true, lane);      // d E_v
       f32x4 Ev[NT];
       rff_embed<D, BF16>(Ev, inv, c_acv, lane, quad, phv);                                                           // recomputed
       f32x4 dT[TT];
@@ -841,8 +899,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) mflip[i] = (unsigned)__shfl((int)maskq, ((col >> 2) << 4) | (4 * quad + i), 64) >> (col & 3);
       }
-      panel_gemm_flip<KB, NT, BF16, ST_DD, NW, true, INIT_BIAS>(
-          acc, F, P, ring, pQ1, gQ1, lane,
+      panel_gemm_flip<KB, NT, BF16, ST_DD, NW, true, INIT_BIAS, LA>(
+          acc, F, P, ring, pQ1, LA ? (more ? pQ1 : NO_STAGE) : gQ1, lane,
           [&](int mt) { const float bc = c_bq1[16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
           [&](int mt, const f32x4& af) {
             float r0, r1, r2, r3;
@@ -878,7 +936,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       Frags<BF16, KB> FA;
       make_frags<BF16, KB>(FA, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA1], srow, D, FA, quad);
-      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO>(acc, FA, P, ring, gQ1, more ? pQ1 : NO_STAGE, true, lane);   // d E_q
+      panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(acc, FA, P, ring, gQ1, more ? (LA ? pV1 : pQ1) : NO_STAGE, true, lane);   // d E_q
       f32x4 dT[TT];
       rff_embed_bwd<D>(dT, acc, E);
       Frags<BF16, D / 64> FT;

@@ -67,6 +67,9 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #ifndef ENF_ZFOLD_WAVES
 #define ENF_ZFOLD_WAVES 8
 #endif
+#ifndef ENF_K2_LA             // z-fold bf16: look-ahead staging (enf_device.h: panel_gemm<.., LA>).  OFF: measured 3 % SLOWER on this
+#define ENF_K2_LA 0           // kernel (decode shape 1.275 vs 1.238 ms same-box, gpurun_out/r02/ab_la3.log): every stage here is followed
+#endif                        // by a vector epilogue longer than the DMA, which the 2-slot order already hides; in K3 it pays (-7 %)
 #ifndef ENF_ANTIPHASE
 #define ENF_ANTIPHASE false
 #endif
@@ -134,6 +137,11 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   if constexpr (ZFOLD) P.rs2 = make_blob_rsrc(A.wz + (size_t)b * A.Z * H * PANEL_DD, (unsigned)(A.Z * H * PANEL_DD));
   else P.rs2 = P.rs;
   first_stage<ST_DD, NW, ENF_ANTIPHASE>(P, ring, pQ1, wave, lane);
+  // look-ahead staging: all five panels of a z-fold bf16 iteration are single 32 KB (8 KB) stages, so the stage after next is
+  // issued behind each stage's closing barrier and streams under the vector epilogue that follows every stage of this kernel;
+  // call sites pass `LA ? <stage after next> : <next stage>`
+  constexpr bool LA = ZFOLD && BF16 && ENF_K2_LA != 0 && !ENF_ANTIPHASE && Cfg::DD::SPP == 1;
+  if constexpr (LA) stage_issue_p<ST_DD, NW>(P, pV1, ring + STAGE_MAX, lane);
 
   // softmax state against a per-column reference logit (the first one seen); fp32 accumulators
   float sm_m[H], sm_l[H], sm_c[H];
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       make_frags<BF16, KB>(F, acc);
       K2_BIAS(acc, c_bq1);
       STAMP(1);
-      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pQ1, pV1, active, lane, c_bq1);
+      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pQ1, LA ? pF : pV1, active, lane, c_bq1);
       STAMP(2);
       const bool mread = K2_MASK_MODE == 2;                       // wave-uniform
       if (K2_MASK_MODE) {
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       make_frags<BF16, KB>(F, acc);
       K2_BIAS(acc, c_bv1);
       STAMP(4);
-      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pV1, pF, active, lane, c_bv1);
+      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pV1, LA ? STAGE_RS2 | (unsigned)(z * H * PANEL_DD) : pF, active, lane, c_bv1);
       STAMP(5);
       const bool mread = K2_MASK_MODE == 2;
       if (K2_MASK_MODE) {
@@ -242,7 +250,11 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       if (!mread) relu_frags<BF16, KB>(F);
       K2_BIAS(acc, c_bf);
       STAMP(6);
-      if constexpr (ZFOLD) panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc, F, P, ring, pF, STAGE_RS2 | (unsigned)(z * H * PANEL_DD), active, lane, c_bf);
+      if constexpr (ZFOLD) {
+        const unsigned wz0 = STAGE_RS2 | (unsigned)(z * H * PANEL_DD);
+        const unsigned after = H > 1 ? wz0 + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE);
+        panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pF, LA ? after : wz0, active, lane, c_bf);
+      }
       else panel_gemm<KB, NT, BF16, ST_GB, NW, K2_INIT>(acc, F, P, ring, pF, pGB, active, lane, c_bf);
       STAMP(7);
       gelu_tiles<NT, BF16>(acc);
@@ -263,8 +275,10 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
         const unsigned wzh = STAGE_RS2 | (unsigned)((z * H + h) * PANEL_DD);
         K2_BIAS(v, zv + H * D + h * D);
         STAMP(10 + 4 * h);
-        panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT>(v, F, P, ring, wzh, h + 1 < H ? wzh + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE),
-                                                 active, lane, zv + H * D + h * D);
+        const bool more = it + 1 < iters;
+        const unsigned nx1 = h + 1 < H ? wzh + PANEL_DD : (more ? pQ1 : NO_STAGE);
+        const unsigned nx2 = h + 2 < H ? wzh + 2 * PANEL_DD : (h + 2 == H ? (more ? pQ1 : NO_STAGE) : (more ? pV1 : NO_STAGE));
+        panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(v, F, P, ring, wzh, LA ? nx2 : nx1, active, lane, zv + H * D + h * D);
       } else {
         f32x4 dummy[1];
         gb_panel<D, BF16, ST_DD, false, NW>(v, dummy, F, P, ring, pGB + h * PANEL_GB, pM, active, c_bgb + 2 * h * D,

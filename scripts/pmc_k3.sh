@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the forward pair kernel (scripts/prof_fwd.py bwd); summaries -> gpurun_out/pmc_<tag>/
+# PMC passes (SQ counters, then FETCH_SIZE / WRITE_SIZE each in a pass of its own) over the pair kernels at the fit shape (scripts/prof_fwd.py bwd); summaries -> gpurun_out/pmc_<tag>/
 # usage: scripts/pmc_k3.sh TAG  (run on the GPU box through gpurun)
 TAG=${1:-k3}
 REPO=$PWD
@@ -12,7 +12,8 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
-           "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS"; do
+           "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $REPO/scripts/prof_fwd.py bwd > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
 done

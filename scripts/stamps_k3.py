@@ -17,9 +17,16 @@ lib = _lib.load()
 buf = (ctypes.c_ulonglong * (8 * 4 * 24))()
 assert lib.enf_debug_read_stamps_bwd(buf) == 0
 a = np.array(buf, dtype=np.int64).reshape(8, 4, 24)
-names = {1: "q-fwd", 2: "v-fwd", 3: "gb0", 4: "mixer0", 5: "gelu/LN/softmax-bwd0", 6: "gM0", 7: "film-bwd0", 9: "gb1", 10: "mixer1",
-         11: "gelu/LN/softmax-bwd1", 12: "gM1", 13: "film-bwd1", 15: "gGB1", 16: "v-bwd", 17: "q-bwd"}
-order = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 15, 16, 17]
+# the z-fold kernel (what the fit shape runs) stamps 4 + 6h / 5 + 6h / 6 + 6h per head; the unfolded one 3 .. 7 + 6h
+zf = a[0, 1, 3] == 0
+if zf:
+    names = {1: "q-fwd", 2: "v-fwd", 4: "a5-gemm0", 5: "gelu/LN/softmax-bwd0", 6: "dn+flips0", 10: "a5-gemm1", 11: "gelu/LN/softmax-bwd1",
+             12: "dn+flips1", 15: "LN-bwd", 16: "v-bwd", 17: "q-bwd"}
+    order = [1, 2, 4, 5, 6, 10, 11, 12, 15, 16, 17]
+else:
+    names = {1: "q-fwd", 2: "v-fwd", 3: "gb0", 4: "mixer0", 5: "gelu/LN/softmax-bwd0", 6: "gM0", 7: "film-bwd0", 9: "gb1", 10: "mixer1",
+             11: "gelu/LN/softmax-bwd1", 12: "gM1", 13: "film-bwd1", 15: "gGB1", 16: "v-bwd", 17: "q-bwd"}
+    order = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 15, 16, 17]
 for w in (0, 4):
     for ti in (1, 2):
         t = a[w, ti]
