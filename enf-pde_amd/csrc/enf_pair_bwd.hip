@@ -54,6 +54,9 @@
 #ifndef ENF_K3_ZF_FUSED       // z-fold heads: gelu(a5) and gelu'(a5) from one exp + rcp (a5 is overwritten by its gelu')
 #define ENF_K3_ZF_FUSED 1
 #endif
+#ifndef ENF_K3_UF_FUSED       // unfolded heads: the same
+#define ENF_K3_UF_FUSED 1
+#endif
 #ifndef ENF_K3_DY2            // z-fold heads: read d ybar twice instead of keeping it in 32 registers across the head's vector phase
 #define ENF_K3_DY2 0
 #endif
@@ -710,7 +713,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #endif
       // mixer LN stats; v <- n~ = (gelu(a5) - mu) * rstd
       float mu2, r2;
-#if ENF_K3_FUSED_GELU
+#if ENF_K3_UF_FUSED
+      // as in the z-fold heads: v = gelu(a5), a5 <- gelu'(a5) from one exp + rcp per element, one tile at a time
+      K3_SCHED_FENCE();
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float g, d;
+          gelu_fg1(a5[t][i], g, d);
+          v[t][i] = g;
+          a5[t][i] = d;
+        }
+        asm volatile("" : "+v"(v[t]), "+v"(a5[t]));
+        K3_SCHED_FENCE();
+      }
+#elif ENF_K3_FUSED_GELU
 #pragma unroll
       for (int t = 0; t < NT; ++t) v[t] = a5[t];
       gelu_fg_tiles<NT>(v, a5);             // v = gelu(a5); a5 <- gelu'(a5)
@@ -735,28 +753,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t + 4 * quad);
       }
 #endif
-      float s0 = 0.f;
+      float s0 = 0.f, sd = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s0 = fmaf(dy[t][i], v[t][i], s0);
+        for (int i = 0; i < 4; ++i) { s0 = fmaf(dy[t][i], v[t][i], s0); sd += dy[t][i]; }
       const float datt = xquad_sum(s0);
       dlogit[h] = nvalid ? att[h] * (datt - A.delta[qrow * H + h]) : 0.f;
       const float ah = nvalid ? att[h] : 0.f;
-      // LayerNorm backward (d n~ = ah * dy), then gelu backward
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { dy[t][i] *= ah; s1 += dy[t][i]; s2 = fmaf(dy[t][i], v[t][i], s2); }
-      const float m1 = xquad_sum(s1) * A.inv_d, m2 = xquad_sum(s2) * A.inv_d;
+      // LayerNorm backward of d n~ = ah * dy (its means follow from the sums above: mean(ah dy) = ah mean(dy),
+      // mean(ah dy n~) = ah datt / D), then gelu backward
+      const float m1 = ah * xquad_sum(sd) * A.inv_d, m2 = ah * datt * A.inv_d;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         // the pre-activation goes through an opaque copy: otherwise hipcc keeps x^2, the exponent and the sigmoid of
         // all 32 elements alive from gelu() above to share them with gelu'() here -- ~100 registers, all spilled
         K3_OPAQUE(a5[t]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dy[t][i] = r2 * (dy[t][i] - m1 - v[t][i] * m2) * (ENF_K3_FUSED_GELU ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
+        for (int i = 0; i < 4; ++i)
+          dy[t][i] = r2 * (fmaf(ah, dy[t][i], -m1) - v[t][i] * m2) * ((ENF_K3_FUSED_GELU || ENF_K3_UF_FUSED) ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
         K3_SCHED_FENCE();     // one tile's transcendental chain at a time: interleaving all 32 costs ~100 live registers
       }
       BSTAMP(5 + 6 * h);
