@@ -188,8 +188,9 @@ int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t x_bstride,
 /* ---------------------------------------------------------------------------------------------
  * Training path: gradients w.r.t. the network weights (value_and_grad over params['nef'],
  * pde_trainer.py:255; nonmaml_pde_trainer.py:304-339).  The per-pair chain (97 % of the FLOPs)
- * stays in HIP; folds, latent prologue and tail -- per-latent / per-query work -- are run by the
- * host framework as differentiable ops around these two entry points.
+ * stays in HIP -- enf_pair_forward for the values, enf_backward_weights for d lt and the gradients of the ENF_P_* tensors --;
+ * folds, latent prologue and tail (per-latent / per-query work) are run by the host framework as differentiable ops around
+ * them.
  *   latent table `lt` (B*Z rows, enf_lt_layout): [ u (H*D) | v0 (H*D) | pose (4) | wcoef | pad | c (H) | pad ]
  *     u, c   : att[n,z,h] = h1[n,z,:].u[z,h,:] + c[z,h]        (fold 1)
  *     v0     : a_to_v(a_norm)                                   (ECA:94)
