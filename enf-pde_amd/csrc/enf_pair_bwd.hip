@@ -92,8 +92,19 @@ __device__ unsigned long long enf_stamps_bwd[8 * 4 * 24];
 extern "C" int enf_debug_read_stamps_bwd(unsigned long long* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(enf_stamps_bwd), sizeof(enf_stamps_bwd)) == hipSuccess ? 0 : -1;
 }
+// workgroup-level stamps (kernel entry, tile loop start / end, exit) of workgroups 7, 263, 519, 775 (one per round at 256 CUs)
+__device__ unsigned long long enf_stamps_bwd_wg[4 * 8 * 4];
+#define WSTAMP(k)                                                                                             \
+  do {                                                                                                        \
+    if ((blockIdx.x & 255) == 7 && blockIdx.x < 1024 && blockIdx.y == 0 && lane == 0)                         \
+      enf_stamps_bwd_wg[((blockIdx.x >> 8) * 8 + wave) * 4 + (k)] = __builtin_amdgcn_s_memtime();             \
+  } while (0)
+extern "C" int enf_debug_read_stamps_bwd_wg(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(enf_stamps_bwd_wg), sizeof(enf_stamps_bwd_wg)) == hipSuccess ? 0 : -1;
+}
 #else
 #define BSTAMP(k) do {} while (0)
+#define WSTAMP(k) do {} while (0)
 #endif
 
 #ifdef ENF_TEST_HOOKS
@@ -347,6 +358,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // measured, scripts/ubench/) -- and found and removed one real defect of the same symptom (inline-asm relu behind
   // compiler-scheduled MFMAs, enf_device.h: relu_f).  The remaining effect was never observed with this barrier (0 of ~5000
   // duplicate-wave checks, tests/test_gpu_backward.py::test_duplicate_waves_agree) and its mechanism is still open: DESIGN.md.
+  WSTAMP(0);
   __syncthreads();
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
@@ -450,6 +462,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   const int split_tiles = (ntiles - split + A.nsplit - 1) / A.nsplit;  // tiles split, split+nsplit, ..
   // ZF: the 8 waves share the sweep (wave w takes every 8th tile of the split); all run the same number of steps
   const int my_tiles = ZF ? (split_tiles + NW - 1) / NW : split_tiles;
+  WSTAMP(1);
   for (int ti = 0; ti < my_tiles; ++ti) {
     const int tk = ZF ? ti * NW + wave : ti;
     const bool tvalid = tk < split_tiles;
@@ -1005,6 +1018,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     }
   }
 #endif
+  WSTAMP(2);
   // ---- fold the partial sums and add this wave's share into the latent-table gradient
   if (!active) return;   // no barrier follows
   float* drow = A.dlt + (size_t)bz * ltstride;
@@ -1045,6 +1059,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       if (lane == 0) atomicAdd(drow + enf_lt_off_ext(H, D) + k, a);
     }
   }
+  WSTAMP(3);
 }
 
 template <int D, int H, bool BF16, bool STORE, bool ZF>

@@ -35,3 +35,16 @@ for w in (0, 4):
             d[names[k]] = int(t[k] - t[prev]); prev = k
         print(f"wave {w} tile {ti} total {int(t[17]-t[0])} gap_to_next {int(a[w,ti+1,0]-t[17])}")
         print("   ", d)
+
+# workgroup-level: entry / loop start / loop end / exit of one workgroup per round (the four that land on the same CU slot)
+try:
+    wg = (ctypes.c_ulonglong * (4 * 8 * 4))()
+    assert lib.enf_debug_read_stamps_bwd_wg(wg) == 0
+    w = np.array(wg, dtype=np.int64).reshape(4, 8, 4)
+    t0 = w[0, :, 0].min()
+    for r in range(4):
+        e, ls, le, x = (w[r, :, k] for k in range(4))
+        print(f"round {r}: entry {int(e.min() - t0)}..{int(e.max() - t0)}  prologue {int((ls - e).mean())}  loop {int((le - ls).mean())}  "
+              f"epilogue {int((x - le).mean())}  exit {int(x.max() - t0)}")
+except AttributeError:
+    pass
