@@ -54,6 +54,9 @@
 #ifndef ENF_K3_ZF_FUSED       // z-fold heads: gelu(a5) and gelu'(a5) from one exp + rcp (a5 is overwritten by its gelu')
 #define ENF_K3_ZF_FUSED 1
 #endif
+#ifndef ENF_K3_A3_FUSED       // value chain: park gelu'(a3) (from the sigmoid gelu(a3) needs anyway) instead of a3
+#define ENF_K3_A3_FUSED 1
+#endif
 #ifndef ENF_K3_UF_FUSED       // unfolded heads: the same
 #define ENF_K3_UF_FUSED 1
 #endif
@@ -542,7 +545,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
       if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a3, F, P, ring, pF, LA ? STAGE_RS2 | (unsigned)PANEL_DD : STAGE_RS2, true, lane, c_bf);
       else panel_gemm<KB, NT, BF16, ST_GB, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, pGB, true, lane, c_bf);
-#if ENF_K3_FUSED_GELU
+#if ENF_K3_A3_FUSED
+      // nh = gelu(a3), a3 <- gelu'(a3) from one exp + rcp per element (one tile at a time, as in the heads); the backward
+      // needs nothing else of a3, so gelu'(a3) is what gets parked
+      K3_SCHED_FENCE();
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float g, d;
+          gelu_fg1(a3[t][i], g, d);
+          nh[t][i] = g;
+          a3[t][i] = d;
+        }
+        asm volatile("" : "+v"(nh[t]), "+v"(a3[t]));
+        K3_SCHED_FENCE();
+      }
+#elif ENF_K3_FUSED_GELU
 #pragma unroll
       for (int t = 0; t < NT; ++t) nh[t] = a3[t];
       gelu_fg_tiles<NT>(nh, a3);            // nh = gelu(a3); a3 <- gelu'(a3), all the backward needs of it
@@ -878,7 +897,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         const f32x4 nht = nh[t], a3t = a3[t];
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dnh[t][i] = r1 * (dnh[t][i] - m1 - nht[i] * m2) * (ENF_K3_FUSED_GELU ? a3t[i] : gelu_grad_f(a3t[i]));   // d a3
+        for (int i = 0; i < 4; ++i) dnh[t][i] = r1 * (dnh[t][i] - m1 - nht[i] * m2) * ((ENF_K3_FUSED_GELU || ENF_K3_A3_FUSED) ? a3t[i] : gelu_grad_f(a3t[i]));   // d a3
         K3_SCHED_FENCE();
       }
       make_frags<BF16, KB>(F, dnh);
