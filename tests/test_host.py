@@ -30,6 +30,14 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.enf_abi_version() == 2
+    # the product library exports the header and nothing for tests: the layout self-tests, the K3 epilogue dump and the
+    # removed process-wide setters live in libenf_hip_test.so / nowhere
+    for name in ("enf_debug_gemm", "enf_debug_pack", "enf_test_read_wave_sums", "enf_set_zfold", "enf_set_zfold_bwd", "enf_set_relu_masks"):
+        assert not hasattr(lib, name), name
+    from enf_pde_amd import _lib
+    tl = _lib.load_test()
+    for name in list(declared) + ["enf_debug_gemm", "enf_debug_pack", "enf_test_read_wave_sums"]:
+        assert hasattr(tl, name), name
 
 
 def test_desc_struct_matches_header():
