@@ -505,6 +505,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-meta", action="store_true", help="skip the outer-step leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run ONLY the per-kernel legs and print them (for rocprofv3 --kernel-trace --stats: the profile then "
+                         "holds exactly the launches the legs time, so its per-kernel averages are the legs' launch_ms)")
     args = ap.parse_args()
     ensure_world(args)
 
@@ -523,6 +526,13 @@ def main():
     coords = coords_of(c, c["grid"], device)
     dcoords = coords_of(c, c.get("decode_grid") or c["grid"], device)
     img = synth_targets(c, coords, c["B"], 100 + rank, device)
+
+    if args.roofline_only:
+        if world != 1:
+            raise SystemExit("bench.py --roofline-only runs on one GPU")
+        legs = pair_kernel_rooflines(c, m, device)
+        print(json.dumps({"roofline_kernels": {k: v for k, v in legs}, "config": {"workload": f"{c['name']}_b{c['B']}_per_gpu"}}), flush=True)
+        return
 
     for _ in range(args.warmup):
         step(c, m, coords, dcoords, img)

@@ -218,7 +218,7 @@ def test_training_path_matches_inference_path(cuda):
 
 
 def test_relu_masks_replay(cuda):
-    """enf_set_relu_masks: masks written at a point and replayed AT THE SAME POINT change nothing (the linearised relu
+    """EnfDesc.mask_mode: masks written at a point and replayed AT THE SAME POINT change nothing (the linearised relu
     equals the relu there), forward and every gradient; replayed at a perturbed point they differ from the free relu."""
     cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=8, O=1, freq=(0.5, 1.0))
     prm = R.init_params(5, cfg, jitter=0.1)
@@ -251,6 +251,38 @@ def test_relu_masks_replay(cuda):
     assert not torch.equal(o2, o3)
     o4, _ = run(p)                              # the setting is consumed: the next pass is a plain one again
     assert torch.equal(o4, o0)
+
+
+def test_relu_masks_replay_in_chunked_passes(cuda, monkeypatch):
+    """The outer step's difference pass runs 2B signals against masks taken for B (signal b replays b % B): when the
+    activation store is chunked, a chunk starts at a signal offset and must still pick its own masks (EnfDims.mask_b0)."""
+    from enf_pde_amd.enf.models import _train
+    from enf_pde_amd.fitting.trainers.pde_trainer import _tree_from_tensors
+    cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=8, O=1, freq=(0.5, 1.0))
+    prm = R.init_params(5, cfg, jitter=0.1)
+    B, N, Z = 3, 40, 9
+    x, p, a, s = make_inputs(cfg, 2 * B, N, Z, 6)
+    nef = build_nef(cfg, "f32")
+    P = nef.load_params(prm, device=cuda)
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    w = t(np.random.default_rng(7).standard_normal((2 * B, N, 1)))
+    buf = nef.relu_mask_buffer(B, N, Z, cuda)
+    with torch.no_grad(), nef.relu_masks(buf, "write", B):
+        nef.apply(P, t(x[:B]), t(p[:B] + 0.03), t(a[:B]), t(s[:B]))         # masks at a nearby point: replaying them matters
+
+    def run():
+        ws = [v.detach().clone().requires_grad_(True) for v in nef.param_tensors(P)]
+        pa, aa = t(p, True), t(a, True)
+        with nef.relu_masks(buf, "read", B):
+            out = nef.apply(_tree_from_tensors(ws), t(x), pa, aa, t(s))
+            g = torch.autograd.grad((out * w).sum(), ws + [pa, aa], allow_unused=True)
+        return [gi for gi in g if gi is not None]
+    one = run()
+    per_b = Z * N * 64 * (7 + 8) * 4
+    monkeypatch.setattr(_train, "STORE_BUDGET_BYTES", B * per_b + (1 << 20))      # B of the 2B signals per chunk
+    two = run()
+    for u, v in zip(one, two):
+        assert float((u - v).abs().max()) <= 2e-5 * float(u.abs().max()) + 1e-30
 
 
 @pytest.mark.parametrize("case", range(8))
