@@ -214,7 +214,11 @@ def decode_step(c, m, dcoords, lat):
     if c.get("rollout"):
         from enf_pde_amd.fitting import solve_latent_ode
         with torch.no_grad():
-            f = lambda z, _t: m.ode.apply(m.ode_params, z)
+            # the inference roll-out of the trainer (MetaSGDPDETrainer.rollout(graph=True), what val_step runs): every
+            # derivative evaluation replays ONE captured hipGraph (PonitaODEGen.graphed), captured once per shape
+            if getattr(m, "ode_graph", None) is None:
+                m.ode_graph = m.ode.graphed(m.ode_params, (p, a, s))
+            f = lambda z, _t: m.ode_graph(z)
             tp, ta, ts = solve_latent_ode(f, (p, a, s), 0, c["rollout"], 1, method="euler")     # (B, 41, Z, .)
         p, a, s = (v.reshape(-1, *v.shape[2:]).contiguous() for v in (tp, ta, ts))
     return decode(m.nef, m.params, dcoords, p, a, s)
