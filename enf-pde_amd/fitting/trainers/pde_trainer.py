@@ -177,9 +177,9 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
         if second_order == "none":
             continue
         w = {k: (torch.zeros_like(lam[k]) if masked(k) else lrs[k] * lam[k]) for k in lam}
-        wmax = max(float(v.abs().max()) for v in w.values())
-        if wmax == 0.0:
-            continue
+        # the step size stays on the device (no host synchronisation inside the outer step): eps = fd_step / max|w|; a
+        # direction that vanishes identically gives plus == minus, a zero difference, and a finite c below -- no contribution
+        wmax = torch.stack([v.abs().max() for v in w.values()]).max().clamp_min(1e-30)
         eps = fd_step / wmax
         plus = {k: phis[s][k] + eps * w[k] for k in lam}
         minus = {k: phis[s][k] - eps * w[k] for k in lam}
@@ -187,8 +187,8 @@ def meta_gradients(nef, nef_params, latents0, lrs, coords, img, masks, optimize_
         # difference is the almost-everywhere second derivative (what jax.grad of the inner steps computes) instead of
         # also counting the units that flip between phi_s - eps w and phi_s + eps w
         gw_d, gl_d = _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys, relu_bufs[s])
-        c = B / (2.0 * eps)
-        g_theta = list(torch._foreach_add(g_theta, gw_d, alpha=-c))
+        c = B / (2.0 * eps)                                                     # a 0-dim device tensor
+        g_theta = list(torch._foreach_sub(g_theta, torch._foreach_mul(gw_d, c)))
         lam = {k: lam[k] - c * gl_d[k] if k in gl_d else lam[k] for k in lam}
     g_lat0 = {k: lam[k].sum(dim=0, keepdim=True) for k in lam}
     return loss, {"nef": g_theta, "autodecoder": g_lat0, "meta_sgd_lrs": g_alpha}
