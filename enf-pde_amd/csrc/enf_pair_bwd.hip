@@ -54,6 +54,9 @@
 #ifndef ENF_K3_ZF_FUSED       // z-fold heads: gelu(a5) and gelu'(a5) from one exp + rcp (a5 is overwritten by its gelu')
 #define ENF_K3_ZF_FUSED 1
 #endif
+#ifndef ENF_STORE_NT          // activation store (STORE instantiation): non-temporal stores
+#define ENF_STORE_NT 0
+#endif
 #ifndef ENF_K3_A3_FUSED       // value chain: park gelu'(a3) (from the sigmoid gelu(a3) needs anyway) instead of a3
 #define ENF_K3_A3_FUSED 1
 #endif
@@ -132,7 +135,14 @@ DEV void store_frags(void* base, size_t row, int D, const Frags<BF16, KB>& F, in
   if constexpr (BF16) {
     __bf16* p = reinterpret_cast<__bf16*>(base) + row * D;
 #pragma unroll
-    for (int blk = 0; blk < KB; ++blk) *reinterpret_cast<bf16x8*>(p + 32 * blk + 8 * quad) = F.f[blk];
+    for (int blk = 0; blk < KB; ++blk) {
+#if ENF_STORE_NT
+      // written once, read once by enf_xtd_kernel, 2 GB per pass: streaming stores keep it out of the way of the panels in L2
+      __builtin_nontemporal_store(__builtin_bit_cast(f32x4, F.f[blk]), reinterpret_cast<f32x4*>(p + 32 * blk + 8 * quad));
+#else
+      *reinterpret_cast<bf16x8*>(p + 32 * blk + 8 * quad) = F.f[blk];
+#endif
+    }
   } else {
     float* p = reinterpret_cast<float*>(base) + row * D;
 #pragma unroll

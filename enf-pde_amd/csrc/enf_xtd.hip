@@ -23,6 +23,10 @@
 #include "enf_launch.h"
 #include "enf_device.h"
 
+#ifndef ENF_XTD_NT            // read-once store: non-temporal loads
+#define ENF_XTD_NT 1
+#endif
+
 namespace {
 
 constexpr int XTD_THREADS = 256, XTD_WAVES = 4, XTD_TILE = 32;      // pairs per K-step
@@ -114,8 +118,13 @@ __global__ __launch_bounds__(XTD_THREADS, 2) void enf_xtd_kernel(XtdArgs A) {
       const int idx = tid + c * XTD_THREADS, row = idx / CH_ROW, ch = idx % CH_ROW;
       const long long gr = row0 + row;
       if (gr < r1) {
+#if ENF_XTD_NT
+        gx[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + ((size_t)gr * D * ES + 16 * ch)));
+        gd[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Dl + ((size_t)gr * D * ES + 16 * ch)));
+#else
         gx[c] = *reinterpret_cast<const f32x4*>(X + ((size_t)gr * D * ES + 16 * ch));
         gd[c] = *reinterpret_cast<const f32x4*>(Dl + ((size_t)gr * D * ES + 16 * ch));
+#endif
       } else {
         gx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         gd[c] = f32x4{0.f, 0.f, 0.f, 0.f};
