@@ -104,7 +104,7 @@ def _full_grads(nef, weights, coords, img, masks, s, lat, keys):
 def _diff_grads(nef, weights, coords, img, masks, s, plus, minus, keys, relu_buf=None):
     """grads(plus) - grads(minus) of the step-s loss, w.r.t. the weights and the latents, in ONE training-path pass: the two
     latent sets run as one batch of 2B signals whose second half enters the loss with a minus sign (the outer step is
-    launch-bound, so one pass of twice the batch costs about half of two passes)."""
+    bound by its many small kernels, so one pass of twice the batch costs about half of two passes)."""
     B = img.shape[0]
     w = [t.detach().requires_grad_(True) for t in weights]
     leaves = {k: torch.cat([plus[k], minus[k]], 0).detach().requires_grad_(True) for k in plus}
