@@ -102,7 +102,7 @@ class _RowDense(torch.autograd.Function):
 
 
 def _dense(x, W, b):
-    return _RowDense.apply(x, W, b) if x.numel() // x.shape[-1] >= 2 * SPLIT_K and not _NO_SPLIT else x @ W + b
+    return _RowDense.apply(x, W, b) if x.numel() // x.shape[-1] >= 2 * SPLIT_K and not _NO_SPLIT else Fnn.linear(x, W.t(), b)
 
 
 class _PairFunction(torch.autograd.Function):
@@ -195,6 +195,10 @@ class _PairFunction(torch.autograd.Function):
 def _ln(x, g, b, n_true):
     """LayerNorm over the last axis whose first-n_true-per-block features are real and the rest zero padding
     (the affine's zero-padded scale / bias clears the padded outputs): statistics divide by n_true."""
+    if n_true == x.shape[-1]:
+        # no padding: the framework's fused LayerNorm (one kernel forward, two backward, instead of ~13 / ~25 element-wise and
+        # reduction launches: the outer step is bound by exactly those, DESIGN.md "Training path")
+        return Fnn.layer_norm(x, (n_true,), g, b, LN_EPS)
     mu = x.sum(-1, keepdim=True) / n_true
     var = (x * x).sum(-1, keepdim=True) / n_true - mu * mu
     return (x - mu) * torch.rsqrt(var.clamp_min(0) + LN_EPS) * g + b
@@ -211,10 +215,11 @@ def latent_table(model, W, p, a, sigma, lay, stem=True, inv=None):
     H, D = model._Hp, model._Dp
     B, Z = p.shape[:2]
     inv = inv if inv is not None else model.cross_attn_invariant
-    s = a @ W["stem_w"] + W["stem_b"] if stem else a                      # NEF:220
+    lin = lambda t, w, b_: Fnn.linear(t, w.t(), b_)                       # x @ W + b as ONE kernel (W is (in, out))
+    s = lin(a, W["stem_w"], W["stem_b"]) if stem else a                   # NEF:220
     an = _ln(s, W["lna_g"], W["lna_b"], model.num_hidden)                 # NEF:56 / ECB
-    k = (an @ W["k_w"] + W["k_b"]).view(B, Z, H, D)                       # ECA:93
-    v0 = an @ W["v_w"] + W["v_b"]                                         # ECA:94
+    k = lin(an, W["k_w"], W["k_b"]).view(B, Z, H, D)                      # ECA:93
+    v0 = lin(an, W["v_w"], W["v_b"])                                      # ECA:94
     scale = 1.0 / math.sqrt(model.num_hidden)                             # ECA:59 (the true width, not a padded one)
     qw = W["q_w"].view(D, H, D)
     mu = scale * torch.einsum("ij,jhd->hid", W["rq_w2"], qw)              # (H, D_in, D) : logits = h1 . (mu_h k_h)
@@ -278,7 +283,7 @@ def tail(model, W, ybar):
     H, D = model._Hp, model._Dp
     B, N, _ = ybar.shape
     y = ybar.view(B, N, H, D) * W["mx_g"] + W["mx_be"]
-    y = (y @ W["mx_w1"] + W["mx_b1"]).reshape(B, N, H * D)               # ECA:16-21 (mixer Dense_1)
+    y = Fnn.linear(y, W["mx_w1"].t(), W["mx_b1"]).reshape(B, N, H * D)    # ECA:16-21 (mixer Dense_1)
     y = _dense(y, W["ao_w"], W["ao_b"])                                   # ECA out_proj
     f = _dense(_ln(_gelu(_dense(y, W["ff_w0"], W["ff_b0"])), W["ff_g"], W["ff_be"], model.num_heads * model.num_hidden),
                W["ff_w1"], W["ff_b1"])
