@@ -3,13 +3,13 @@
 The reference differentiates ``nef.apply`` w.r.t. ``params['nef']`` with ``jax.value_and_grad``
 (experiments/fitting/trainers/pde_trainer.py:255, nonmaml_pde_trainer.py:304-339).  Here the
 per-pair chain -- all but ~3 % of the arithmetic -- stays in the HIP kernels
-(``enf_pair_forward`` / ``enf_pair_backward``, include/enf_hip.h); what is per-latent or per-query
+(``enf_pair_forward`` / ``enf_backward_weights``, include/enf_hip.h); what is per-latent or per-query
 (the weight folds, the latent prologue, the tail after the softmax-weighted sum) is expressed as
 ordinary differentiable device ops around it so that autograd carries the gradient from the
 "effective" per-pair parameters and the latent table back to the Flax-named tensors.
 
-The backward kernel materialises each per-pair layer's input and delta (bf16 in bf16 mode), and
-every per-pair weight gradient is then one GEMM  dW = X^T delta  over the pair axis.
+``enf_backward_weights`` is one library call: the backward pair kernel materialises each per-pair layer's input and delta
+(bf16 in bf16 mode) in the call's scratch and ``enf_xtd_kernel`` turns them into every  dW = X^T delta  and bias sum.
 """
 import ctypes
 import math

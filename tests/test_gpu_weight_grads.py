@@ -1,4 +1,4 @@
-"""Weight-gradient parity: the training path (HIP pair kernels + per-pair dW GEMMs + differentiable
+"""Weight-gradient parity: the training path (HIP pair kernels, enf_backward_weights for every per-pair dW, differentiable
 prologue / tail) against fp64 autograd of the torch oracle over every tensor of the parameter
 tree -- what the reference gets from jax.value_and_grad over params['nef']
 (pde_trainer.py:255, nonmaml_pde_trainer.py:304-339)."""
