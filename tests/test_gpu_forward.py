@@ -121,3 +121,53 @@ def test_forward_config3_sphere(cuda, invariant, precision):
     cfg = make_cfg(invariant, D=128, H=2, C=32, O=3, freq=(0.2, 0.4))
     err, mse = run_case(cuda, cfg, B=2, N=700, Z=128, precision=precision, seed=31)
     assert err < TOL[precision] and mse < 1e-5
+
+
+def test_latent_table_is_reused_only_for_the_same_latents(cuda):
+    """A forward on the same latent tensors and weights as the last call on the workspace (a decode right after the fit's
+    final-loss forward) skips the prologue kernel; any change of the latents -- another tensor, or the same one modified in
+    place -- or of the weights must not."""
+    import ctypes
+    from enf_pde_amd import _lib
+    cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
+    prm = R.init_params(21, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 3, 300, 16, 22)
+    nef = build_nef(cfg, "f32")
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    xs, xl = t(x[:, :40]), t(x)
+    tp, ta, ts = t(p), t(a), t(s)
+    calls = []
+    lib = _lib.load()
+    orig = lib.enf_forward_stages
+
+    class Spy:                                   # records the `stages` argument of every forward
+        def __call__(self, *args):
+            calls.append(int(args[-2]))
+            return orig(*args)
+    spy = Spy()
+    try:
+        lib.enf_forward_stages = spy
+        with torch.no_grad():
+            nef.apply(params, xl, tp, ta, ts)                 # sizes the cached workspace for the larger call
+            calls.clear()
+            small = nef.apply(params, xs, tp, ta, ts)         # "final-loss forward" on few points
+            full = nef.apply(params, xl, tp, ta, ts)          # "decode": same latents, same weights
+            assert [c & 1 for c in calls] == [0, 0]           # both found the table of the first call
+            fresh = build_nef(cfg, "f32")
+            ref = fresh.apply(fresh.load_params(prm, device=cuda), xl, tp, ta, ts)
+            assert torch.equal(full, ref) and torch.equal(small, ref[:, :40])
+            calls.clear()
+            ta.add_(0.05)                                     # same tensor, new contents
+            moved = nef.apply(params, xl, tp, ta, ts)
+            assert calls[-1] & 1 == 1 and not torch.equal(moved, full)
+            assert torch.equal(moved, fresh.apply(fresh.load_params(prm, device=cuda), xl, tp, ta, ts))
+            calls.clear()
+            nef.apply(params, xl, tp.clone(), ta, ts)         # another tensor with the same values: no reuse either
+            assert calls[-1] & 1 == 1
+            prm2 = R.init_params(22, cfg, jitter=0.1)
+            calls.clear()
+            other = nef.apply(nef.load_params(prm2, device=cuda), xl, tp.clone(), ta, ts)     # other weights
+            assert calls[-1] & 1 == 1 and not torch.equal(other, moved)
+    finally:
+        lib.enf_forward_stages = orig
