@@ -1049,8 +1049,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #endif
   WSTAMP(2);
   // ---- fold the partial sums and add this wave's share into the latent-table gradient
-  if (!active) return;   // no barrier follows
+  if (!active) return;   // (unfolded: a wave without a latent; no barrier follows on that path.  z-fold: all eight waves share the latent)
   float* drow = A.dlt + (size_t)bz * ltstride;
+#if ENF_K3_LDSACC
+  if constexpr (ZF) {
+    // the eight waves of a z-fold workgroup share one latent: their partial sums are added through LDS first -- wave w folds
+    // slots w, w + 8, ... over the waves (fixed order) and the quads -- so a gradient element gets ONE atomic per workgroup
+    // (one per launch with nsplit = 1: then the sum is order-independent) instead of eight on the same address
+    __syncthreads();
+    const float* lall = reinterpret_cast<const float*>(smem + SM::LACC) + lane;      // [wave][slot][lane]
+    constexpr int NS = 2 * H * NT;
+    for (int sl = wave; sl < NS; sl += NW) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += lall[(w * NS + sl) * 64];
+      v = xquad_sum(v);
+      if (quad == 0)
+        atomicAdd(drow + (sl < H * NT ? enf_lt_off_u(H, D) + 16 * sl : enf_lt_off_v0(H, D) + 16 * (sl - H * NT)) + col, v);
+    }
+  } else
+#endif
 #pragma unroll
   for (int h = 0; h < H; ++h)
 #pragma unroll
