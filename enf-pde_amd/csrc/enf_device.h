@@ -508,12 +508,15 @@ template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd
 // sphere -> (phi, theta, sin theta, cos theta).  sx/cx = sin/cos(theta_x) (sphere only).
 struct QueryPt { float x0, x1, x2, sx, cx; };
 
-DEV QueryPt load_query(const float* xp, int dx, int inv_id) {
+DEV QueryPt make_query(float x0, float x1, float x2, int inv_id) {
   QueryPt q;
-  q.x0 = xp[0]; q.x1 = dx > 1 ? xp[1] : 0.f; q.x2 = dx > 2 ? xp[2] : 0.f;
+  q.x0 = x0; q.x1 = x1; q.x2 = x2;
   q.sx = 0.f; q.cx = 0.f;
   if (inv_id == ENF_INV_LATITUDE_PERIODIC || inv_id == ENF_INV_POLAR_PERIODIC || enf_inv_has_phase(inv_id)) { q.sx = sinf(q.x1); q.cx = cosf(q.x1); }
   return q;
+}
+DEV QueryPt load_query(const float* xp, int dx, int inv_id) {
+  return make_query(xp[0], dx > 1 ? xp[1] : 0.f, dx > 2 ? xp[2] : 0.f, inv_id);
 }
 
 // `ext`: the latent's 16-float extension (LDS, wave-uniform): ball -> the rotation matrix R (row-major)

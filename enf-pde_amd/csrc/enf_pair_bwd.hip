@@ -54,6 +54,15 @@
 #ifndef ENF_K3_ZF_FUSED       // z-fold heads: gelu(a5) and gelu'(a5) from one exp + rcp (a5 is overwritten by its gelu')
 #define ENF_K3_ZF_FUSED 1
 #endif
+#ifndef ENF_K3_PREFETCH       // per-tile global reads (query coordinates, lse) issued one tile ahead.  OFF: measured 1.4 % SLOWER
+#define ENF_K3_PREFETCH 0     // on the fit (2.74 -> 2.78 ms same-box, gpurun_out/r02/ab_pf.log): the five live registers cost more
+#endif                        // than the exposed L2 latency at the top of a tile; with delta prefetched too, +25 spilled dwords
+#if ENF_K3_PREFETCH
+#define K3_LSE(h) t_lse[h]
+#else
+#define K3_LSE(h) A.lse[qrow * H + (h)]
+#endif
+#define K3_DELTA(h) A.delta[qrow * H + (h)]     // (delta is wanted late in the tile: prefetching it costs 25 spilled dwords)
 #ifndef ENF_STORE_NT          // activation store (STORE instantiation): non-temporal stores
 #define ENF_STORE_NT 0
 #endif
@@ -476,6 +485,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // ZF: the 8 waves share the sweep (wave w takes every 8th tile of the split); all run the same number of steps
   const int my_tiles = ZF ? (split_tiles + NW - 1) / NW : split_tiles;
   WSTAMP(1);
+  // this lane's query of tile step `ts` (clamped to a valid row): the per-tile global reads -- coordinates, lse -- are
+  // issued one tile ahead (ENF_K3_PREFETCH), under the previous tile's last GEMM stage, instead of at the top of the tile
+  // where nothing hides their latency
+  auto tile_query = [&](int ts) {
+    const int tk_ = ZF ? ts * NW + wave : ts;
+    const int n0_ = tk_ < split_tiles ? (split + tk_ * A.nsplit) * 16 : 0;
+    return min(n0_ + col, A.N - 1);
+  };
+#if ENF_K3_PREFETCH
+  float pf_x[3], pf_lse[H];
+  auto prefetch = [&](int ts) {
+    const int n_ = tile_query(ts);
+    const float* xp = A.x + (size_t)b * A.x_bstride + (size_t)n_ * A.dx;
+    pf_x[0] = xp[0]; pf_x[1] = A.dx > 1 ? xp[1] : 0.f; pf_x[2] = A.dx > 2 ? xp[2] : 0.f;
+    const size_t qr = (size_t)b * A.N + n_;
+#pragma unroll
+    for (int h = 0; h < H; ++h) pf_lse[h] = A.lse[qr * H + h];
+  };
+  if (my_tiles > 0) prefetch(0);
+#endif
   for (int ti = 0; ti < my_tiles; ++ti) {
     const int tk = ZF ? ti * NW + wave : ti;
     const bool tvalid = tk < split_tiles;
@@ -483,7 +512,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     const bool nvalid = tvalid && n0 + col < A.N;
     const int n = min(n0 + col, A.N - 1);
     const size_t qrow = (size_t)b * A.N + n;
+#if ENF_K3_PREFETCH
+    float t_lse[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) t_lse[h] = pf_lse[h];
+    const QueryPt q = make_query(pf_x[0], pf_x[1], pf_x[2], A.inv);
+#else
     const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
+#endif
     float inv[4], win;
     pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, ext);
     const size_t srow = (size_t)bzc * A.N + n;        // row of the materialised activations (STORE)
@@ -517,7 +553,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           for (int i = 0; i < 4; ++i) s = fmaf(masked ? acc[t][i] : fmaxf(acc[t][i], 0.f), u[i], s);
         }
         const float lg = xquad_sum(s) + cz[h] + win;
-        att[h] = __expf(lg - A.lse[qrow * H + h]);
+        att[h] = __expf(lg - K3_LSE(h));
       }
     }
     BSTAMP(1);
@@ -660,7 +696,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         }
 #endif
         const float datt = xquad_sum(s0);
-        dlogit[h] = nvalid ? att[h] * (datt - A.delta[qrow * H + h]) : 0.f;
+        dlogit[h] = nvalid ? att[h] * (datt - K3_DELTA(h)) : 0.f;
         const float ah = nvalid ? att[h] : 0.f;
         // LayerNorm backward of the weighted cotangent ah * dy: its two means follow from the sums above,
         // mean(ah dy) = ah mean(dy),  mean(ah dy v) = ah datt / D
@@ -801,7 +837,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 = fmaf(dy[t][i], v[t][i], s0); sd += dy[t][i]; }
       const float datt = xquad_sum(s0);
-      dlogit[h] = nvalid ? att[h] * (datt - A.delta[qrow * H + h]) : 0.f;
+      dlogit[h] = nvalid ? att[h] * (datt - K3_DELTA(h)) : 0.f;
       const float ah = nvalid ? att[h] : 0.f;
       // LayerNorm backward of d n~ = ah * dy (its means follow from the sums above: mean(ah dy) = ah mean(dy),
       // mean(ah dy n~) = ah datt / D), then gelu backward
@@ -993,6 +1029,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       Frags<BF16, KB> FA;
       make_frags<BF16, KB>(FA, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA1], srow, D, FA, quad);
+#if ENF_K3_PREFETCH
+      if (more) prefetch(ti + 1);          // the next tile's coordinates / lse land under this stage
+#endif
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(acc, FA, P, ring, gQ1, more ? (LA ? pV1 : pQ1) : NO_STAGE, true, lane);   // d E_q
       f32x4 dT[TT];
       rff_embed_bwd<D>(dT, acc, E);
