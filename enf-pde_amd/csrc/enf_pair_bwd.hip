@@ -485,6 +485,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // ZF: the 8 waves share the sweep (wave w takes every 8th tile of the split); all run the same number of steps
   const int my_tiles = ZF ? (split_tiles + NW - 1) / NW : split_tiles;
   WSTAMP(1);
+#if ENF_K3_PREFETCH
   // this lane's query of tile step `ts` (clamped to a valid row): the per-tile global reads -- coordinates, lse -- are
   // issued one tile ahead (ENF_K3_PREFETCH), under the previous tile's last GEMM stage, instead of at the top of the tile
   // where nothing hides their latency
@@ -493,7 +494,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     const int n0_ = tk_ < split_tiles ? (split + tk_ * A.nsplit) * 16 : 0;
     return min(n0_ + col, A.N - 1);
   };
-#if ENF_K3_PREFETCH
   float pf_x[3], pf_lse[H];
   auto prefetch = [&](int ts) {
     const int n_ = tile_query(ts);
