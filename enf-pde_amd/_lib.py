@@ -11,7 +11,7 @@ TEST_LIB_PATH = os.path.join(_HERE, "libenf_hip_test.so")    # same ABI + test h
 ENF_NUM_TENSORS = 46
 PREC = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic": 2, "ponita": 3,
-                 "abs_pos": 4, "rel_pos": 5, "norm_rel_pos": 6, "ball": 7, "ball_lat": 8}
+                 "abs_pos": 4, "rel_pos": 5, "norm_rel_pos": 6, "ball": 7, "ball_lat": 8, "ponita_full": 9}
 
 EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",

@@ -58,6 +58,7 @@ extern "C" int enf_check_desc(const EnfDesc* d) {
   const bool two_d = d->invariant_id == ENF_INV_REL_POS_PERIODIC || d->invariant_id == ENF_INV_PONITA ||
                      d->invariant_id == ENF_INV_LATITUDE_PERIODIC || d->invariant_id == ENF_INV_POLAR_PERIODIC;
   if (two_d && d->dx != 2) return ENF_EDIM;     // reference: assert cfg.num_in == 2 (invariant/__init__.py:62,65)
+  if (d->invariant_id == ENF_INV_PONITA_FULL && d->dx != 3) return ENF_EDIM;   // queries (pos_x, pos_y, theta)
   if (enf_inv_has_phase(d->invariant_id) && d->D != 64) return ENF_EUNSUPPORTED;   // (the 128-wide backward kernel has no LDS left)
   if (enf_inv_has_phase(d->invariant_id) && d->dx != 3) return ENF_EDIM;   // ball, ball_lat: (phi, theta, r) coordinates
   if (!(d->D == 64 || d->D == 128)) return ENF_EUNSUPPORTED;

@@ -513,6 +513,7 @@ DEV QueryPt make_query(float x0, float x1, float x2, int inv_id) {
   q.x0 = x0; q.x1 = x1; q.x2 = x2;
   q.sx = 0.f; q.cx = 0.f;
   if (inv_id == ENF_INV_LATITUDE_PERIODIC || inv_id == ENF_INV_POLAR_PERIODIC || enf_inv_has_phase(inv_id)) { q.sx = sinf(q.x1); q.cx = cosf(q.x1); }
+  else if (inv_id == ENF_INV_PONITA_FULL) { q.sx = sinf(q.x2); q.cx = cosf(q.x2); }      // the query's own orientation
   return q;
 }
 DEV QueryPt load_query(const float* xp, int dx, int inv_id) {
@@ -566,10 +567,12 @@ DEV void pair_invariant(int inv_id, int dx, const QueryPt& q, const f32x4& pz, f
         win = __expf(-ang * ang * wcoef);
       }
     } break;
+    case ENF_INV_PONITA_FULL:                  // ponita.py:80-92: the two below and the orientations' inner product
     case ENF_INV_PONITA: {                     // ponita.py:30-44; window _base_invariant.py:25-33
       const float r0 = q.x0 - pz[0], r1 = q.x1 - pz[1];
       inv[0] = r0 * pz[2] + r1 * pz[3];
       inv[1] = -r0 * pz[3] + r1 * pz[2];
+      if (inv_id == ENF_INV_PONITA_FULL) inv[2] = q.cx * pz[2] + q.sx * pz[3];
       if (use_window) win = -wcoef * (r0 * r0 + r1 * r1);
     } break;
     default: {                                 // abs_pos.py:42, rel_pos.py:41, norm_rel_pos.py:34

@@ -45,6 +45,7 @@ ENF_HD inline int enf_inv_dim(int inv, int dx) {
     case ENF_INV_LATITUDE_PERIODIC: return 4;
     case ENF_INV_POLAR_PERIODIC: return 1;
     case ENF_INV_PONITA: return 2;
+    case ENF_INV_PONITA_FULL: return 3;
     case ENF_INV_ABS_POS: return dx;
     case ENF_INV_REL_POS: return dx;
     case ENF_INV_NORM_REL_POS: return 1;
@@ -59,6 +60,7 @@ ENF_HD inline int enf_inv_pose_dim(int inv, int dx) {
     case ENF_INV_LATITUDE_PERIODIC: return 2;
     case ENF_INV_POLAR_PERIODIC: return 2;
     case ENF_INV_PONITA: return 3;            // (pos_x, pos_y, theta)
+    case ENF_INV_PONITA_FULL: return 3;
     case ENF_INV_ABS_POS: return dx;
     case ENF_INV_REL_POS: return dx;
     case ENF_INV_NORM_REL_POS: return dx;

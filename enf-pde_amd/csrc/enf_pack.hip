@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
       float wc;
       const float sg = A.sigma ? A.sigma[r] : 1.f;
       const bool sphere = A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC || enf_inv_has_phase(A.inv);
-      if (A.inv == ENF_INV_PONITA) { q[0] = pp[0]; q[1] = pp[1]; q[2] = cosf(pp[2]); q[3] = sinf(pp[2]); }
+      if (A.inv == ENF_INV_PONITA || A.inv == ENF_INV_PONITA_FULL) { q[0] = pp[0]; q[1] = pp[1]; q[2] = cosf(pp[2]); q[3] = sinf(pp[2]); }
       else if (sphere) { q[0] = pp[0]; q[1] = pp[1]; q[2] = sinf(pp[1]); q[3] = cosf(pp[1]); }    // ball: (alpha, beta) play (phi, theta) in the window
       else { for (int i = 0; i < A.dp && i < 3; ++i) q[i] = pp[i]; }
       wc = sphere ? 1.f / (2.f * sg * sg) : 1.f / (sg * sg);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
       const float* pp = A.p + (size_t)r * A.dp_dim;
       float* o = A.dp + (size_t)r * A.dp_dim;
       const bool sph = A.inv == ENF_INV_LATITUDE_PERIODIC || A.inv == ENF_INV_POLAR_PERIODIC || enf_inv_has_phase(A.inv);
-      if (A.inv == ENF_INV_PONITA) { o[0] = g[0]; o[1] = g[1]; o[2] = -sinf(pp[2]) * g[2] + cosf(pp[2]) * g[3]; }
+      if (A.inv == ENF_INV_PONITA || A.inv == ENF_INV_PONITA_FULL) { o[0] = g[0]; o[1] = g[1]; o[2] = -sinf(pp[2]) * g[2] + cosf(pp[2]) * g[3]; }
       else if (sph) { o[0] = g[0]; o[1] = g[1] + cosf(pp[1]) * g[2] - sinf(pp[1]) * g[3]; }
       else { for (int i = 0; i < A.dp_dim && i < 3; ++i) o[i] = g[i]; }
       if (enf_inv_has_phase(A.inv)) {

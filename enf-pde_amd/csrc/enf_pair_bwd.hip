@@ -307,19 +307,25 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
         }
       }
     } break;
+    case ENF_INV_PONITA_FULL:
     case ENF_INV_PONITA: {
       const float r0 = q.x0 - pz[0], r1 = q.x1 - pz[1];
       float dr0 = dinv[0] * pz[2] - dinv[1] * pz[3];
       float dr1 = dinv[0] * pz[3] + dinv[1] * pz[2];
       dpose[2] += dinv[0] * r0 + dinv[1] * r1;
       dpose[3] += dinv[0] * r1 - dinv[1] * r0;
+      float dth = 0.f;                                   // d / d theta_x of inv[2] = cos(theta_x) c_p + sin(theta_x) s_p
+      if (inv_id == ENF_INV_PONITA_FULL) {
+        dpose[2] += dinv[2] * q.cx; dpose[3] += dinv[2] * q.sx;
+        dth = dinv[2] * (-q.sx * pz[2] + q.cx * pz[3]);
+      }
       if (use_window) {                                   // win = -wc |r|^2
         dwc += dwin * (-(r0 * r0 + r1 * r1));
         dr0 += dwin * (-2.f * wcoef * r0);
         dr1 += dwin * (-2.f * wcoef * r1);
       }
       dpose[0] -= dr0; dpose[1] -= dr1;
-      if (dxq) { dxq[0] = dr0; dxq[1] = dr1; dxq[2] = 0.f; }
+      if (dxq) { dxq[0] = dr0; dxq[1] = dr1; dxq[2] = dth; }
     } break;
     default: {
       const float r0 = q.x0 - pz[0], r1 = dx > 1 ? q.x1 - pz[1] : 0.f, r2 = dx > 2 ? q.x2 - pz[2] : 0.f;

@@ -179,10 +179,7 @@ class EquivariantCrossAttentionNeF:
             # latent self-attention (NEF:223-226) runs the same pair kernels with the latents' own positions as queries
             # (enf/models/_train.py: apply_layers); dormant in every shipped config, so only the plain shapes are served
             if self.self_attn_invariant.name not in _lib.INVARIANT_IDS:
-                raise NotImplementedError(f"self-attention with the '{self.self_attn_invariant.name}' invariant (queries "
-                                          "that carry an orientation) is not built")
-            if self._Dp != self.num_hidden or self._Hp != self.num_heads:
-                raise NotImplementedError("num_layers > 0 is served at the kernels' native widths / head counts only")
+                raise NotImplementedError(f"self-attention with the '{self.self_attn_invariant.name}' invariant is not built")
         self.embedding_type = embedding_type
         self.embedding_freq_multiplier = tuple(embedding_freq_multiplier)
         self.condition_value_transform = condition_value_transform

@@ -63,6 +63,27 @@ AXES = ([(None, "D"), ("D",), ("D",), ("D",)] + _RFF + _RFF + _KB("D", "HD") * 3
 assert len(AXES) == 46
 
 
+# a latent self-attention block (NEF:137-167): the attention's 30 tensors as above (ENF_W_LNA_G .. ENF_W_MX_B1), then out_proj
+# HD -> D (project_heads) and a D -> D -> D FFN
+BLOCK_AXES = AXES[2:32] + _KB("HD", "D") + _FFN("D", "D", "D")
+assert len(BLOCK_AXES) == 38
+
+
+def _pad_list(tensors, axes, D, Dp, H, Hp):
+    out = []
+    for t, kinds in zip(tensors, axes):
+        for ax, kind in enumerate(kinds):
+            t = _pad_axis(t, ax, kind, D, Dp, H, Hp)
+        out.append(t)
+    return out
+
+
+def pad_block_tensors(tensors, D, Dp, H, Hp=None):
+    """The 38 tensors of one self-attention block of a (width D, H heads) model as a (width Dp, Hp heads) block."""
+    Hp = H if Hp is None else Hp
+    return list(tensors) if D == Dp and H == Hp else _pad_list(tensors, BLOCK_AXES, D, Dp, H, Hp)
+
+
 def pad_tensors(tensors, D, Dp, H, Hp=None):
     """The 46 weight tensors (ENF_W_* order) of a (width D, H heads) model as a (width Dp, Hp heads) model."""
     Hp = H if Hp is None else Hp

@@ -228,7 +228,7 @@ def latent_table(model, W, p, a, sigma, lay, stem=True, inv=None):
     c = torch.einsum("hd,bzhd->bzh", cvec, k)
     name = inv.name
     zero = p.new_zeros(B, Z, 1)
-    if name == "ponita":
+    if name in ("ponita", "ponita_full"):
         pose = torch.cat([p[..., :2], torch.cos(p[..., 2:3]), torch.sin(p[..., 2:3])], -1)
     elif name in ("latitude_periodic", "polar_periodic", "ball", "ball_lat"):
         pose = torch.cat([p[..., :2], torch.sin(p[..., 1:2]), torch.cos(p[..., 1:2])], -1)
@@ -303,45 +303,56 @@ assert len(W_NAMES) == _lib.ENF_NUM_TENSORS
 
 
 class _SelfAttnView:
-    """The pair kernels' descriptor for a latent self-attention block: queries = the latents' own positions, the
-    self-attention invariant (NEF:223-226)."""
+    """The pair kernels' descriptor for a latent self-attention block: queries = the latents' own positions (and, for
+    Ponita2D, orientations), the self-attention invariant (NEF:223-226)."""
 
     def __init__(self, model):
         self._m = model
         self._Hp, self._Dp, self.precision = model._Hp, model._Dp, model.precision
         self.num_hidden, self.num_heads = model.num_hidden, model.num_heads
         self._x_arg = model._x_arg
+        self.pair_variants, self.default_pair_variants = model.pair_variants, model.default_pair_variants
 
-    def _desc(self, B, N, Z):
+    def _desc(self, B, N, Z, masks=None):
         m, inv = self._m, self._m.self_attn_invariant
-        return _lib.make_desc(B, N, Z, m._Hp, m._Dp, m.latent_dim, m.num_out, inv.num_x_pos_dims, inv.kernel_id,
-                              m.use_gaussian_window, _lib.PREC[m.precision])
+        return _lib.make_desc(B, N, Z, m._Hp, m._Dp, m.latent_dim, m.num_out, inv.num_x_pos_dims + inv.num_x_ori_dims,
+                              inv.kernel_id, m.use_gaussian_window, _lib.PREC[m.precision],
+                              d_true=m.num_hidden if m._Dp != m.num_hidden else 0, h_true=m.num_heads if m._Hp != m.num_heads else 0,
+                              variants=tuple(_lib.VARIANT[v] for v in (m.pair_variants or m.default_pair_variants)), masks=masks)
 
 
 def apply_layers(model, tensors, x, p, a, sigma):
     """nef.apply with num_layers > 0 (NEF:204-235): stem, the latent self-attention blocks -- each one the attention
     operator over (p, p) on the HIP pair kernels between differentiable per-latent ops --, then the cross-attention
     block on the hidden latents and the output MLP.  Differentiable w.r.t. the latents (poses included: the pair backward
-    also returns the query-side gradient, the queries of a self-attention block being the poses) and every weight."""
+    also returns the query-side gradient, the queries of a self-attention block being the poses) and every weight.
+    A narrow model runs zero-padded in the kernels' width like the layer-free one (_pad.py)."""
     n0 = _lib.ENF_NUM_TENSORS
-    W = dict(zip(W_NAMES, tensors[:n0]))
+    Dt, Ht, D, H = model.num_hidden, model.num_heads, model._Dp, model._Hp
+    blocks = [tensors[n0 + 38 * i:n0 + 38 * (i + 1)] for i in range(model.num_layers)]
+    head = tensors[:n0]
+    if D != Dt or H != Ht:
+        head = _pad.pad_tensors(head, Dt, D, Ht, H)
+        blocks = [_pad.pad_block_tensors(b, Dt, D, Ht, H) for b in blocks]
+    W = dict(zip(W_NAMES, head))
     blk = W_NAMES[2:40]                                                    # the 38 tensors of one attention block
-    D, HD = model.num_hidden, model.num_heads * model.num_hidden
+    HD = H * D
     B, Z = p.shape[:2]
     sa = model.self_attn_invariant
     s = a @ W["stem_w"] + W["stem_b"]                                     # NEF:220
     view = _SelfAttnView(model)
-    xq = p[..., :sa.num_x_pos_dims]                                       # queries of a self-attention block: x = p (differentiable)
+    xq = p[..., :sa.num_x_pos_dims + sa.num_x_ori_dims]                   # queries of a self-attention block: x = p (differentiable;
+                                                                          # Ponita2D: position and the raw angle, embedded in-kernel)
     lay = lt_layout(view._desc(B, Z, Z))
     for i in range(model.num_layers):
-        Wi = dict(zip(blk, tensors[n0 + 38 * i:n0 + 38 * (i + 1)]))
+        Wi = dict(zip(blk, blocks[i]))
         lt = latent_table(view, Wi, p, s, sigma, lay, stem=False, inv=sa)
         ybar = _PairFunction.apply(xq, lt, view, *effective_pair_params(view, Wi))            # (B, Z, HD)
-        y = ybar.view(B, Z, model.num_heads, D) * Wi["mx_g"] + Wi["mx_be"]
+        y = ybar.view(B, Z, H, D) * Wi["mx_g"] + Wi["mx_be"]
         y = (y @ Wi["mx_w1"] + Wi["mx_b1"]).reshape(B, Z, HD)                                  # ECA:16-21 (mixer Dense_1)
         a_attn = y @ Wi["ao_w"] + Wi["ao_b"]                                                   # ECA:150 (project_heads: HD -> D)
         r = s + a_attn                                                                         # NEF:62-64 (residual)
-        f = _ln(_gelu(r @ Wi["ff_w0"] + Wi["ff_b0"]), Wi["ff_g"], Wi["ff_be"], D) @ Wi["ff_w1"] + Wi["ff_b1"]
+        f = _ln(_gelu(r @ Wi["ff_w0"] + Wi["ff_b0"]), Wi["ff_g"], Wi["ff_be"], Dt) @ Wi["ff_w1"] + Wi["ff_b1"]
         s = _gelu(s + f)                                                                       # NEF:225-226
     desc = model._desc(B, x.shape[1], Z)
     _lib.check(_lib.load().enf_check_desc(ctypes.byref(desc)))

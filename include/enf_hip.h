@@ -44,7 +44,9 @@ enum {
   ENF_INV_NORM_REL_POS = 6,      /* norm_rel_pos.py:34                                           */
   ENF_INV_BALL = 7,              /* ball.py:54-96: [R(alpha,beta,gamma) x^, r_x, r_p], window :36-52 (64-wide kernels only) */
   ENF_INV_BALL_LAT = 8,          /* ball_lat.py:54-88: [th_x, th_p, cos dphi, sin dphi, r_x, r_p]                              */
-  ENF_INV_COUNT = 9
+  ENF_INV_PONITA_FULL = 9,       /* ponita.py:48-92 (Ponita2D): both sides carry an orientation, x = (pos_x, pos_y, theta_x), dx = 3:
+                                    [ponita's two, cos(theta_x - theta_p)]; the self-attention invariant of `ponita` (INV/__init__.py:30-32) */
+  ENF_INV_COUNT = 10
 };
 
 /* arithmetic of the per-pair contractions */

@@ -34,7 +34,9 @@ def _flat(tree, prefix=""):
             yield prefix + k, tree[k]
 
 
-@pytest.mark.parametrize("inv,D,H,L,Z", [("rel_pos_periodic", 64, 2, 2, 9), ("polar_periodic", 128, 2, 1, 18), ("rel_pos", 64, 1, 3, 5)])
+@pytest.mark.parametrize("inv,D,H,L,Z", [("rel_pos_periodic", 64, 2, 2, 9), ("polar_periodic", 128, 2, 1, 18), ("rel_pos", 64, 1, 3, 5),
+                                         ("ponita", 64, 2, 2, 9), ("ponita", 128, 1, 1, 16),      # self-attention = Ponita2D: queries with an orientation
+                                         ("rel_pos_periodic", 32, 2, 1, 6), ("ponita", 16, 3, 2, 5)])   # zero-padded to 64 wide (3 -> 4 heads)
 def test_layers_match_oracle(cuda, inv, D, H, L, Z):
     cfg = dict(make_cfg(inv, D=D, H=H, C=8, O=2, freq=(0.5, 1.0)), num_layers=L)
     # (seeds: with D + L / L one relu pre-activation of the rel_pos_periodic case sits within fp32 rounding of zero and its
@@ -116,5 +118,13 @@ def test_layers_inner_loop_and_init_shapes(cuda):
     masks = torch.stack([torch.randperm(16)[:8] for _ in range(3)], 1).to(cuda)
     loss, lat = inner_loop(nef, P, lat0, default_meta_sgd_lrs(8, lr_p=0.1, device=cuda), coords, img, masks)
     assert torch.isfinite(loss) and not torch.equal(lat["p_pos"], lat0["p_pos"]) and not torch.equal(lat["a"], lat0["a"])
-    with pytest.raises(NotImplementedError):
-        _nef(dict(make_cfg("ponita", D=64, H=2, C=8, O=1), num_layers=1), "f32")      # Ponita2D queries carry an orientation
+    # ponita: the self-attention blocks use Ponita2D (three invariants, queries with an orientation); parameter shapes follow
+    cfgp = dict(make_cfg("ponita", D=64, H=2, C=8, O=1), num_layers=1)
+    nefp = _nef(cfgp, "f32")
+    Pp = nefp.init(0, device=cuda)
+    refp = R.init_params(0, cfgp)
+    assert {k: tuple(v.shape) for k, v in _flat(Pp)} == {k: tuple(v.shape) for k, v in _flat(refp)}
+    xp_, pp_, ap_, sp_ = (torch.tensor(v, dtype=torch.float32, device=cuda) for v in make_inputs(cfgp, 1, 16, 4, 0))
+    latp = {"p_pos": pp_[:1, :, :2], "p_ori": pp_[:1, :, 2:], "a": ap_[:1], "gaussian_window": sp_[:1]}
+    lossp, fitp = inner_loop(nefp, Pp, latp, default_meta_sgd_lrs(8, lr_p=0.1, with_ori=True, device=cuda), xp_[0], img, masks)
+    assert torch.isfinite(lossp) and not torch.equal(fitp["p_ori"], latp["p_ori"])

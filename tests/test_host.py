@@ -74,7 +74,7 @@ def test_check_desc_and_error_mapping(lib):
     assert lib.enf_check_desc(ctypes.byref(ok)) == 0
     assert lib.enf_packed_weight_bytes(ctypes.byref(ok)) > 531585 * 2
     assert lib.enf_workspace_bytes(ctypes.byref(ok)) > 0
-    bad_inv = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 9, 1, 1)
+    bad_inv = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 10, 1, 1)
     with pytest.raises(ValueError, match="Unknown invariant"):
         _lib.check(lib.enf_check_desc(ctypes.byref(bad_inv)))
     bad_dim = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 3, 0, 1, 1)     # rel_pos_periodic needs num_in == 2
@@ -90,6 +90,11 @@ def test_check_desc_and_error_mapping(lib):
     assert lib.enf_invariant_dim(0, 2) == 4 and lib.enf_invariant_dim(2, 2) == 1 and lib.enf_invariant_dim(4, 3) == 3
     assert lib.enf_invariant_pose_dim(3, 2) == 3
     assert lib.enf_invariant_dim(7, 3) == 5 and lib.enf_invariant_dim(8, 3) == 6 and lib.enf_invariant_pose_dim(7, 3) == 4
+    # Ponita2D (the self-attention invariant of ponita): three invariants, queries (pos_x, pos_y, theta)
+    assert lib.enf_invariant_dim(9, 3) == 3 and lib.enf_invariant_pose_dim(9, 3) == 3
+    _lib.check(lib.enf_check_desc(ctypes.byref(_lib.make_desc(2, 16, 16, 2, 64, 8, 1, 3, 9, 1, 0))))
+    with pytest.raises(AssertionError):
+        _lib.check(lib.enf_check_desc(ctypes.byref(_lib.make_desc(2, 16, 16, 2, 64, 8, 1, 2, 9, 1, 0))))
     # ball / ball_lat: 3-d coordinates, 64-wide kernels only
     _lib.check(lib.enf_check_desc(ctypes.byref(_lib.make_desc(2, 100, 25, 4, 64, 32, 1, 3, 7, 1, 1))))
     for bad in (_lib.make_desc(2, 100, 25, 2, 128, 32, 1, 3, 7, 1, 1), _lib.make_desc(2, 100, 25, 4, 64, 32, 1, 2, 8, 1, 1)):
