@@ -154,8 +154,9 @@ def test_model_constructor_errors():
     with pytest.raises(NotImplementedError):
         _nef(embedding_type="polynomial")
     assert len(_nef(num_layers=2).init(0, device="cpu")["params"]) == 5          # + self_attention_blocks_0/1 (NEF:137-167)
+    assert _nef(num_layers=1, num_hidden=32)._Dp == 64                             # layers also run zero-padded (tests/test_gpu_layers.py)
     with pytest.raises(NotImplementedError):
-        _nef(num_layers=1, num_hidden=32)                                          # layers: native kernel widths only
+        _nef(condition_value_transform=False)                                      # no shipped config; DESIGN.md 7
     with pytest.raises(AssertionError):
         _nef(num_hidden=63)
 
