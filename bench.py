@@ -130,29 +130,25 @@ def synth_fields(b, seed, device):
     return coords, synth_targets(_c2, coords, b, seed, device)
 
 
-class _Autodecoder:
+def _Autodecoder(c):
     """The meta autodecoder of a config; config 4's 128 latents sit on a 16 x 8 cell-centred grid (the reference's
     init_positions_grid asserts a square number), window = d / sqrt(Z) by the same d / k rule (autodecoder.py:38-43)."""
-
-    def __new__(cls, c):
-        from enf_pde_amd.enf.latents.autodecoder_meta import PositionOrientationFeatureAutodecoderMeta as AD
-        n_ori = 1 if c["inv"] == "ponita" else 0
-        system = "polar" if c["inv"] in ("latitude_periodic", "polar_periodic") else "cartesian"
-        ad = AD(num_signals=1, num_latents=c["Z"], latent_dim=c["C"], num_pos_dims=2, num_ori_dims=n_ori,
-                gaussian_window_size=-1, coordinate_system=system)
-        k = round(c["Z"] ** 0.5)
-        if system == "cartesian" and k * k != c["Z"]:
-            base_init = ad.init
-
-            def init(key=None, device="cuda", _z=c["Z"], _C=c["C"]):
-                nx = 2 ** math.ceil(math.log2(_z) / 2)
-                ny = _z // nx
-                ax = lambda n: torch.linspace(-1 + 1 / n, 1 - 1 / n, n, dtype=torch.float64)
-                g = torch.stack(torch.meshgrid(ax(nx), ax(ny), indexing="ij"), -1).reshape(1, -1, 2).float()
-                return {"params": {"p_pos": g.to(device), "a": torch.ones(1, _z, _C, device=device),
-                                   "gaussian_window": torch.full((1, _z, 1), 2.0 / math.sqrt(_z), device=device)}}
-            ad.init = init
-        return ad
+    from enf_pde_amd.enf.latents.autodecoder_meta import PositionOrientationFeatureAutodecoderMeta as AD
+    n_ori = 1 if c["inv"] == "ponita" else 0
+    system = "polar" if c["inv"] in ("latitude_periodic", "polar_periodic") else "cartesian"
+    ad = AD(num_signals=1, num_latents=c["Z"], latent_dim=c["C"], num_pos_dims=2, num_ori_dims=n_ori,
+            gaussian_window_size=-1, coordinate_system=system)
+    k = round(c["Z"] ** 0.5)
+    if system == "cartesian" and k * k != c["Z"]:
+        def init(key=None, device="cuda", _z=c["Z"], _C=c["C"]):
+            nx = 2 ** math.ceil(math.log2(_z) / 2)
+            ny = _z // nx
+            ax = lambda n: torch.linspace(-1 + 1 / n, 1 - 1 / n, n, dtype=torch.float64)
+            g = torch.stack(torch.meshgrid(ax(nx), ax(ny), indexing="ij"), -1).reshape(1, -1, 2).float()
+            return {"params": {"p_pos": g.to(device), "a": torch.ones(1, _z, _C, device=device),
+                               "gaussian_window": torch.full((1, _z, 1), 2.0 / math.sqrt(_z), device=device)}}
+        ad.init = init
+    return ad
 
 
 def model_config(c):

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(XTD_THREADS, 2) void enf_xtd_kernel(XtdArgs A) {
   const char* Dl = reinterpret_cast<const char*>(A.Dl[j]);
 
   f32x4 acc[TR][NT];
-  f32x4 bacc[TR * 2 / 2 + 1];                // this wave's share of the bias tiles: delta tiles TR * wave .. + TR - 1
+  f32x4 bacc[TR];                            // this wave's share of the bias tiles: delta tiles TR * wave .. + TR - 1
 #pragma unroll
   for (int a = 0; a < TR; ++a) {
     bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
