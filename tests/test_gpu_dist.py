@@ -93,3 +93,29 @@ def test_bench_spawns_its_own_ranks(cuda):
     assert d["meta_step"]["n_gpus"] == 2 and "gloo" in d["meta_step"]["collective"] and d["meta_step"]["ms_per_step"] > 0
     one = 16 * (4 * 512 + 4096)
     assert abs(d["value"] - 2 * one * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]      # the whole job's points / time
+
+
+@pytest.mark.parametrize("flags", [["--config", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                                   ["--config", "3", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-meta", "--no-roofline"],
+                                   ["--roofline-only"]])
+def test_bench_flags(cuda, flags):
+    """bench.py's other workloads and legs keep running: a BASELINE.json config other than the headline one prints the
+    contract's line with its own workload name; --roofline-only prints the three per-kernel legs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + flags, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    if "--roofline-only" in flags:
+        assert set(d["roofline_kernels"]) == {"decode_fwd", "fit_fwd", "fit_bwd"}
+        assert all(0 < v["frac"] < 1 and v["launch_ms"] > 0 for v in d["roofline_kernels"].values())
+        return
+    cfg = int(flags[1])
+    assert d["config"]["baseline_config"] == cfg and d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "query-points/s"
+    assert f"config {cfg}" in d["metric"] and d["vs_baseline"] is None and d["higher_is_better"] is True
+    if "--no-roofline" not in flags:
+        assert d["roofline"]["kernel"] in ("enf_pair_fwd_kernel", "enf_pair_bwd_kernel") and d["roofline"]["traffic"] is None
+        assert d["meta_step"]["ms_per_step"] > 0
