@@ -54,6 +54,9 @@
 #ifndef ENF_K3_ZF_FUSED       // z-fold heads: gelu(a5) and gelu'(a5) from one exp + rcp (a5 is overwritten by its gelu')
 #define ENF_K3_ZF_FUSED 1
 #endif
+#ifndef ENF_K3_ANTI           // the upper four waves (the SIMD-mates of the lower four) take each stage's barrier BEFORE its MFMAs
+#define ENF_K3_ANTI 0         // (enf_device.h: Pipe.early): one wave of a SIMD multiplies while the other runs its vector epilogue.
+#endif                        // OFF: correct (148 tests) but 9 % SLOWER on the fit (3.00 vs 2.75 ms, gpurun_out/r02/ab_anti.log), as in K2
 #ifndef ENF_K3_PREFETCH       // per-tile global reads (query coordinates, lse) issued one tile ahead.  OFF: measured 1.4 % SLOWER
 #define ENF_K3_PREFETCH 0     // on the fit (2.74 -> 2.78 ms same-box, gpurun_out/r02/ab_pf.log): the five live registers cost more
 #endif                        // than the exposed L2 latency at the top of a tile; with delta prefetched too, +25 spilled dwords
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   constexpr int NW = NWAVES;
   // look-ahead staging: every panel of the z-fold bf16 chain is ONE 32 KB (8 KB at D = 64) stage, so the stage after next
   // can be issued behind each stage's closing barrier; call sites pass `LA ? <stage after next> : <next stage>`
-  constexpr bool LA = ZF && BF16 && ENF_K3_LA != 0 && Cfg::DD::SPP == 1;
+  constexpr bool LA = ZF && BF16 && ENF_K3_LA != 0 && ENF_K3_ANTI == 0 && Cfg::DD::SPP == 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem + SM::RING;
   float* cst = reinterpret_cast<float*>(smem + SM::CONSTS);
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   if constexpr (ZF) P.rs2 = make_blob_rsrc(A.wzt + (size_t)bzc * H * 2 * PANEL_DD, (unsigned)(H * 2 * PANEL_DD));
   else P.rs2 = P.rs;
   const unsigned pWG = (unsigned)A.L.awg;
-  first_stage<ST_DD>(P, ring, pQ1, wave, lane);
+  first_stage<ST_DD, NW, (ENF_K3_ANTI != 0) && ZF>(P, ring, pQ1, wave, lane);
   if constexpr (LA) stage_issue_p<ST_DD, NW>(P, pV1, ring + STAGE_MAX, lane);       // the second stage is in flight from here on
 
   // per-lane partial sums over this wave's queries.  dU/dV0: lane (col, quad) holds feature
@@ -1092,6 +1095,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     }
   }
 #endif
+  pipe_finish(P);          // (antiphase staging only: the early waves take the last stage's barrier here)
   WSTAMP(2);
   // ---- fold the partial sums and add this wave's share into the latent-table gradient
   if (!active) return;   // (unfolded: a wave without a latent; no barrier follows on that path.  z-fold: all eight waves share the latent)
