@@ -206,9 +206,26 @@ DEV f32x4 rowvec(const float* vec, int tile, int quad) {
 }
 
 // sum over the four quads of a column (they hold disjoint feature rows)
+#ifndef ENF_XQ_SWAP
+#define ENF_XQ_SWAP 1
+#endif
+// sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the quads of a 16-column tile), result in all four.
+// ENF_XQ_SWAP: with gfx950's lane-swap instructions (pure VALU: v_permlane32_swap gives [a.lo | b.lo], [a.hi | b.hi],
+// v_permlane16_swap exchanges the odd 16-lane rows of one operand with the even rows of the other) instead of two
+// ds_bpermute_b32 round trips through the LDS crossbar (scripts/ubench/permlane_sum.hip: 112 vs 172 ticks per dependent sum).
+// Inline asm -- the builtin loses its second result in hipcc 7.2 --, with the two wait states a VALU-written operand needs.
 DEV float xquad_sum(float v) {
+#if ENF_XQ_SWAP
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  const float s = a + b;
+  float c = s, d = s;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+  return c + d;
+#else
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
+#endif
 }
 
 // ------------------------------------------------------------------ math

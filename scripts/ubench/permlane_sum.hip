@@ -10,14 +10,12 @@ __device__ __forceinline__ float xq_shfl(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 __device__ __forceinline__ float xq_swap(float v) {
-  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
-  asm volatile("" : "+v"(b));                       // two registers: the swap exchanges halves BETWEEN its operands
-  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);      // a' = [a.lo | b.lo], b' = [a.hi | b.hi]
-  float s = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-  unsigned c = __builtin_bit_cast(unsigned, s), d = c;
-  asm volatile("" : "+v"(d));
-  auto q = __builtin_amdgcn_permlane16_swap(c, d, false, false);      // odd rows of c <-> even rows of d
-  return __builtin_bit_cast(float, q[0]) + __builtin_bit_cast(float, q[1]);
+  // (inline asm: with the builtin, hipcc 7.2 adds the first result to itself -- it loses the second one)
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));      // a = [a.lo | b.lo], b = [a.hi | b.hi]
+  float s = a + b, c = s, d = s;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));      // odd rows of c <-> even rows of d
+  return c + d;
 }
 __global__ void check(const float* in, float* o1, float* o2) {
   const float v = in[threadIdx.x];
