@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ENF_HIP_LIB") or os.path.join(_HERE, "libenf_hip.so")   # ENF_HIP_LIB: A/B builds (scripts/build_variant.sh)
-TEST_LIB_PATH = os.path.join(_HERE, "libenf_hip_test.so")    # same ABI + test hooks (csrc/Makefile); loaded by tests only
+TEST_LIB_PATH = os.environ.get("ENF_HIP_TEST_LIB") or os.path.join(_HERE, "libenf_hip_test.so")    # same ABI + test hooks (csrc/Makefile); tests only
 
 ENF_NUM_TENSORS = 46
 PREC = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}

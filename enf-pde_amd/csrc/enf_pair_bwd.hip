@@ -54,6 +54,9 @@
 #ifndef ENF_K3_ZF_FUSED       // z-fold heads: gelu(a5) and gelu'(a5) from one exp + rcp (a5 is overwritten by its gelu')
 #define ENF_K3_ZF_FUSED 1
 #endif
+#ifndef ENF_K3_ENTRY_BARRIER  // 0 only in investigation builds (scripts/k3_race/README.md): the kernel's first statement
+#define ENF_K3_ENTRY_BARRIER 1
+#endif
 #ifndef ENF_K3_ANTI           // the upper four waves (the SIMD-mates of the lower four) take each stage's barrier BEFORE its MFMAs
 #define ENF_K3_ANTI 0         // (enf_device.h: Pipe.early): one wave of a SIMD multiplies while the other runs its vector epilogue.
 #endif                        // OFF: correct (148 tests) but 9 % SLOWER on the fit (3.00 vs 2.75 ms, gpurun_out/r02/ab_anti.log), as in K2
@@ -390,7 +393,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // compiler-scheduled MFMAs, enf_device.h: relu_f).  The remaining effect was never observed with this barrier (0 of ~5000
   // duplicate-wave checks, tests/test_gpu_backward.py::test_duplicate_waves_agree) and its mechanism is still open: DESIGN.md.
   WSTAMP(0);
+#if ENF_K3_ENTRY_BARRIER
   __syncthreads();
+#endif
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
   const int bz = ZF ? (int)blockIdx.x : blockIdx.x * NW + wave;
