@@ -8,8 +8,8 @@
 // 16-channel x 16-sender tile at a time) and is consumed in registers, so only kb, a and out touch memory.
 //   forward          : out  (also d a: the same contraction with (r, s) swapped and the upstream gradient for a)
 //   backward, basis  : d kb[b,r,s,:] = W (g[b,r,:] * a[b,s,:])
-// d W = kb^T (g (x) a) over the pair axis is a plain GEMM and is left to the library (host side, like the decoder's
-// per-pair weight gradients).  The sum over the MFMA's K index is order-free, so each lane's four K-steps use four
+//   backward, weight : d W = kb^T (g (x) a) over the pair axis, the right operand formed in registers (enf_ode_conv_dw_kernel).
+// The sum over the MFMA's K index is order-free, so each lane's four K-steps use four
 // CONSECUTIVE basis functions / channels (one 16-byte load feeds four MFMAs).
 // (First version: one wave per (b, r, channel tile) -- 8 re-reads of every basis tile and one dependent MFMA chain per
 // wave: 22.5 us per call at B=16, Z=64, J=64, C=128 = 0.31 of the fp32-MFMA peak.)
@@ -17,6 +17,7 @@
 #include "enf_layout.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define OB_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 
 struct OdeConvArgs {
   const float* a;      // (B, Z, C)
@@ -181,6 +182,110 @@ extern "C" int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const flo
   ODE_DKB(4, 1) ODE_DKB(4, 2) ODE_DKB(4, 4) ODE_DKB(4, 8)
   ODE_DKB(8, 1) ODE_DKB(8, 2) ODE_DKB(8, 4)
 #undef ODE_DKB
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+}
+
+// d W[j][c] = sum over (b, r, s) of kb[b,r,s,j] * g[b,r,c] * a[b,s,c]  (SepGconv's weight gradient): a (J x P)(P x C) product
+// over the P = B Z^2 pairs whose right operand g (x) a is formed in registers (the unfused path writes it out: 33 MB per layer
+// at the bench shape, then a split-K library GEMM and two reductions).  The pairs are the MFMA's K index: lane quad q takes
+// senders s0 + 4 q + 0..3 of a 16-sender tile.  A workgroup walks a contiguous share of the (b, r) rows; wave w owns the
+// channel tiles w, w + 4 for every basis tile, accumulates them in registers over the whole share and writes one partial
+// (J, C) per workgroup; enf_ode_sum_partials_kernel adds the partials in a fixed order.
+struct OdeConvDwArgs { const float* a; const float* kb; const float* g; float* part; int B, Z, J, C, rows_per_wg; };
+
+template <int JT, int CK>   // J = 16 JT; CK = channel tiles per wave (C <= 64 CK)
+__global__ __launch_bounds__(256) void enf_ode_conv_dw_kernel(OdeConvDwArgs A) {
+  const int lane = threadIdx.x & 63, col = lane & 15, quad = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = A.C, J = A.J, Z = A.Z, CT = C / 16;
+  f32x4 acc[CK][JT];
+#pragma unroll
+  for (int k = 0; k < CK; ++k)
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) acc[k][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int row0 = blockIdx.x * A.rows_per_wg, row1 = min(row0 + A.rows_per_wg, A.B * Z);
+  const int ST = (Z + 15) / 16, nstep = (row1 - row0) * ST;        // steps = (row, 16-sender tile); operands fetched one step ahead
+  f32x4 av[JT], aa[CK], avn[JT], aan[CK];
+  float gv[CK], gvn[CK];
+  auto fetch = [&](int step, f32x4 (&va)[JT], f32x4 (&vb)[CK], float (&vg)[CK]) {
+    const int row = row0 + step / ST, s0 = 16 * (step % ST), b = row / Z;
+    const float* kbr = A.kb + (size_t)row * Z * J;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = s0 + 4 * quad + r, sc = s < Z ? s : Z - 1;
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) va[jt][r] = kbr[(size_t)sc * J + 16 * jt + col];
+#pragma unroll
+      for (int k = 0; k < CK; ++k)
+        vb[k][r] = (s < Z && wave + 4 * k < CT) ? A.a[((size_t)b * Z + s) * C + 16 * (wave + 4 * k) + col] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < CK; ++k) vg[k] = wave + 4 * k < CT ? A.g[(size_t)row * C + 16 * (wave + 4 * k) + col] : 0.f;
+  };
+  if (nstep > 0) fetch(0, av, aa, gv);
+  for (int step = 0; step < nstep; ++step) {
+    fetch(step + 1 < nstep ? step + 1 : step, avn, aan, gvn);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int k = 0; k < CK; ++k) acc[k][jt] = OB_MFMA4(av[jt][r], gv[k] * aa[k][r], acc[k][jt]);
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) av[jt] = avn[jt];
+#pragma unroll
+    for (int k = 0; k < CK; ++k) { aa[k] = aan[k]; gv[k] = gvn[k]; }
+  }
+  float* part = A.part + (size_t)blockIdx.x * J * C;
+#pragma unroll
+  for (int k = 0; k < CK; ++k) {
+    if (wave + 4 * k < CT) {
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(size_t)(16 * jt + 4 * quad + r) * C + 16 * (wave + 4 * k) + col] = acc[k][jt][r];
+    }
+  }
+}
+
+// out[e] = sum over w of part[w][e], e < n: 32 elements x 8 groups per block, each group a fixed stride-8 share, then the 8
+// group sums in order (bitwise reproducible).
+__global__ __launch_bounds__(256) void enf_ode_sum_partials_kernel(const float* part, int nwg, int n, float* out) {
+  __shared__ float red[8][32];
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+  float s = 0.f;
+  if (e < n)
+    for (int w = grp; w < nwg; w += 8) s += part[(size_t)w * n + e];
+  red[grp][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    float t = 0.f;
+    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x & 31];
+    out[e] = t;
+  }
+}
+
+static int ode_dw_wgs(int B, int Z) { return B * Z < 256 ? B * Z : 256; }
+
+extern "C" size_t enf_ode_conv_backward_weight_scratch_bytes(int B, int Z, int J, int C) {
+  if (ode_check(B, Z, J, C)) return 0;
+  return (size_t)ode_dw_wgs(B, Z) * J * C * 4;
+}
+
+extern "C" int enf_ode_conv_backward_weight(int B, int Z, int J, int C, const float* a, const float* kb, const float* g,
+                                            float* dW, void* scratch, size_t scratch_bytes, void* stream) {
+  int rc = ode_check(B, Z, J, C);
+  if (rc) return rc;
+  if (!a || !kb || !g || !dW || !scratch) return ENF_EINVAL;
+  if (scratch_bytes < enf_ode_conv_backward_weight_scratch_bytes(B, Z, J, C)) return ENF_EINVAL;
+  const int rows = B * Z, nwg0 = ode_dw_wgs(B, Z), rpw = (rows + nwg0 - 1) / nwg0, nwg = (rows + rpw - 1) / rpw;
+  OdeConvDwArgs A{a, kb, g, (float*)scratch, B, Z, J, C, rpw};
+  const int JT = J / 16, CK = C > 64 ? 2 : 1;
+  hipStream_t st = (hipStream_t)stream;
+#define ODE_DW(JT_, CK_) if (JT == JT_ && CK == CK_) hipLaunchKernelGGL((enf_ode_conv_dw_kernel<JT_, CK_>), dim3(nwg), dim3(256), 0, st, A);
+  ODE_DW(1, 1) ODE_DW(2, 1) ODE_DW(4, 1) ODE_DW(8, 1) ODE_DW(1, 2) ODE_DW(2, 2) ODE_DW(4, 2) ODE_DW(8, 2)
+#undef ODE_DW
+  hipLaunchKernelGGL(enf_ode_sum_partials_kernel, dim3((J * C + 31) / 32), dim3(256), 0, st, (const float*)scratch, nwg, J * C, dW);
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
 

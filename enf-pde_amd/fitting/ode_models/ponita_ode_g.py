@@ -13,6 +13,7 @@ through the solver.  Parameters: the reference's flax tree ``{'params': {'ponita
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn.functional as Fnn
@@ -94,8 +95,11 @@ class _SepGconv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dkb = torch.empty_like(kb)
             _lib.launch(a.device, lib.enf_ode_conv_backward_basis, B, Z, J, C, _ptr(a), _ptr(g), _ptr(W), _ptr(dkb), st)
-        if ctx.needs_input_grad[2]:       # d W = kb^T (g (x) a) over the pair axis: a plain GEMM
-            dW = _xt_dot(kb.reshape(-1, J), (g[:, :, None, :] * a[:, None, :, :]).reshape(-1, C))
+        if ctx.needs_input_grad[2]:       # d W = kb^T (g (x) a) over the pair axis, g (x) a formed in registers
+            dW = torch.empty_like(W)
+            n = lib.enf_ode_conv_backward_weight_scratch_bytes(B, Z, J, C)
+            sc = torch.empty(n // 4, device=a.device, dtype=torch.float32)
+            _lib.launch(a.device, lib.enf_ode_conv_backward_weight, B, Z, J, C, _ptr(a), _ptr(kb), _ptr(g), _ptr(dW), _ptr(sc), n, st)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = g.sum((0, 1))
         return da, dkb, dW, db
@@ -155,6 +159,66 @@ class PolynomialFeatures:
         return sum(dim ** k for k in range(1, self.degree + 2))
 
 
+class _KernelBasis(torch.autograd.Function):
+    """kb = gelu(gelu(poly(inv) W1 + b1) W3 + b3) over the B Z^2 pairs in ONE HIP kernel each way (csrc/enf_ode_basis.hip):
+    neither the (B Z^2, F) feature tensor nor the hidden layer exist; the backward recomputes the forward per tile and
+    returns d inv and the four weight gradients (kernel_basis MLP + PolynomialFeatures, ponita_ode_g.py:15-26, 128-131)."""
+
+    @staticmethod
+    def supported(inv, degree, W1, W3, backward):
+        return (inv.is_cuda and inv.dtype == torch.float32 and
+                bool(_lib.load().enf_ode_basis_supported(inv.shape[-1], degree, W1.shape[1], W3.shape[1], int(backward))))
+
+    @staticmethod
+    def _scratch(lib, P, I, H1, J, backward, dev):
+        n = lib.enf_ode_basis_scratch_bytes(P, I, H1, J, backward)
+        return torch.empty(n // 4, device=dev, dtype=torch.float32), n
+
+    @staticmethod
+    def forward(ctx, inv, degree, W1, b1, W3, b3):
+        lib = _lib.load()
+        x = inv.reshape(-1, inv.shape[-1]).contiguous()
+        W1, b1, W3, b3 = W1.contiguous(), b1.contiguous(), W3.contiguous(), b3.contiguous()
+        P, I = x.shape
+        H1, J = W1.shape[1], W3.shape[1]
+        kb = torch.empty((P, J), device=x.device, dtype=torch.float32)
+        sc, n = _KernelBasis._scratch(lib, P, I, H1, J, 0, x.device)
+        _lib.launch(x.device, lib.enf_ode_basis_forward, P, I, degree, H1, J, _ptr(x), _ptr(W1), _ptr(b1), _ptr(W3), _ptr(b3),
+                    _ptr(kb), _ptr(sc), n, _stream(x.device))
+        ctx.save_for_backward(x, W1, b1, W3, b3)
+        ctx.degree, ctx.shape = degree, inv.shape
+        return kb.view(*inv.shape[:-1], J)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, W1, b1, W3, b3 = ctx.saved_tensors
+        P, I = x.shape
+        H1, J = W1.shape[1], W3.shape[1]
+        if not lib.enf_ode_basis_supported(I, ctx.degree, H1, J, 1):
+            raise NotImplementedError(f"fused kernel-basis backward: hidden width {H1} is forward-only")
+        g2 = g.reshape(P, J).contiguous()
+        dx, dW1, db1, dW3, db3 = (torch.empty_like(t) for t in (x, W1, b1, W3, b3))
+        sc, n = _KernelBasis._scratch(lib, P, I, H1, J, 1, x.device)
+        _lib.launch(x.device, lib.enf_ode_basis_backward, P, I, ctx.degree, H1, J, _ptr(x), _ptr(W1), _ptr(b1), _ptr(W3),
+                    _ptr(b3), _ptr(g2), _ptr(dx), _ptr(dW1), _ptr(db1), _ptr(dW3), _ptr(db3), _ptr(sc), n, _stream(x.device))
+        return dx.view(ctx.shape), None, dW1, db1, dW3, db3
+
+
+def kernel_basis(inv, degree, K1, K3, poly=None):
+    """The kernel-basis MLP over the pair invariants: fused where the HIP kernels cover the shape (I <= 4, degree 3, hidden
+    32..128 -- 256 for inference --, basis 32..128), else PolynomialFeatures + two pair-wise Dense layers."""
+    W1, b1, W3, b3 = K1["kernel"], K1["bias"], K3["kernel"], K3["bias"]
+    train = torch.is_grad_enabled() and any(t.requires_grad for t in (inv, W1, b1, W3, b3))
+    if FUSED_BASIS and _KernelBasis.supported(inv, degree, W1, W3, train):
+        return _KernelBasis.apply(inv, degree, W1, b1, W3, b3)
+    poly = poly or PolynomialFeatures(degree)
+    return _gelu(_PairDense.apply(_gelu(_PairDense.apply(poly(inv), W1, b1)), W3, b3))
+
+
+FUSED_BASIS = os.environ.get("ENF_ODE_UNFUSED_BASIS", "0") != "1"      # diagnostic switch (tests, scripts/bench_ode.py): the unfused path
+
+
 def _gelu(x):
     return Fnn.gelu(x, approximate="tanh")                 # flax nn.gelu default
 
@@ -162,6 +226,34 @@ def _gelu(x):
 def _dense(x, p):
     y = x @ p["kernel"]
     return y + p["bias"] if "bias" in p else y
+
+
+class _LatentMLP(torch.autograd.Function):
+    """ConvBlock after the convolution (ponita_ode_g.py:44-48): LayerNorm(eps 1e-6) -> Dense -> gelu -> Dense over the B Z latent
+    rows, with the backward written out: 4 launches forward and 10 backward instead of the ~25 of the op-by-op autograd graph
+    (bias adds fused into the GEMMs, no gradient-buffer fills / accumulations) -- the evaluation is launch-bound."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, W1, b1, W2, b2):
+        H = x.shape[-1]
+        xn, mean, rstd = torch.native_layer_norm(x, (H,), gamma, beta, 1e-6)
+        pre = torch.addmm(b1, xn.reshape(-1, H), W1)
+        h = Fnn.gelu(pre, approximate="tanh")
+        out = torch.addmm(b2, h, W2)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta, xn, pre, h, W1, W2)
+        return out.view(*x.shape[:-1], W2.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd, gamma, beta, xn, pre, h, W1, W2 = ctx.saved_tensors
+        H = x.shape[-1]
+        g2 = g.reshape(-1, g.shape[-1])
+        dW2, db2 = h.t() @ g2, g2.sum(0)
+        dpre = torch.ops.aten.gelu_backward(g2 @ W2.t(), pre, approximate="tanh")
+        dW1, db1 = xn.reshape(-1, H).t() @ dpre, dpre.sum(0)
+        dx, dgamma, dbeta = torch.ops.aten.native_layer_norm_backward((dpre @ W1.t()).view(x.shape), x, (H,), mean, rstd, gamma, beta,
+                                                                      [True, True, True])
+        return dx, dgamma, dbeta, dW1, db1, dW2, db2
 
 
 def _trunc_normal(gen, shape, std, device):
@@ -175,6 +267,23 @@ def _lecun(gen, n_in, n_out, device, bias=True):
     if bias:
         p["bias"] = torch.zeros(n_out, device=device)
     return p
+
+
+def _flatten_tree(tree):
+    """Leaves of a nested dict in sorted-key order, and the function that rebuilds the dict from such a list."""
+    def leaves(t):
+        out = []
+        for k in sorted(t):
+            out += leaves(t[k]) if isinstance(t[k], dict) else [t[k]]
+        return out
+
+    def build(lv):
+        it = iter(lv)
+
+        def rec(t):
+            return {k: (rec(t[k]) if isinstance(t[k], dict) else next(it)) for k in sorted(t)}
+        return rec(tree)
+    return leaves(tree), build
 
 
 class PonitaGen:
@@ -217,15 +326,19 @@ class PonitaGen:
             p = torch.cat((p[..., :zp], torch.cos(p[..., zp:]), torch.sin(p[..., zp:])), -1)
         invariants = inv(p, p)                                                            # (B, Z, Z, I)
         K1, K3 = P["kernel_basis"]["layers_1"], P["kernel_basis"]["layers_3"]
-        kb = _gelu(_PairDense.apply(_gelu(_PairDense.apply(self.poly(invariants), K1["kernel"], K1["bias"])), K3["kernel"], K3["bias"]))
+        kb = kernel_basis(invariants, self.degree, K1, K3, self.poly)
         if self.kernel_size != "global":                                                  # :162-164
             kb = kb * torch.exp(-torch.linalg.norm(p[:, :, None, :] - p[:, None, :, :], dim=-1) / self.kernel_size)[..., None]
         a = _dense(a, P["a_stem"])
         for i in range(self.num_layers):                                                  # ConvBlock, :42-49
             L = P[f"interaction_layers_{i}"]
             x = sep_gconv(a, kb, L["conv"]["kernel"]["kernel"], L["conv"]["bias"])
-            x = Fnn.layer_norm(x, (x.shape[-1],), L["norm"]["scale"], L["norm"]["bias"], 1e-6)
-            a = _dense(_gelu(_dense(x, L["linear_1"])), L["linear_2"])
+            if x.is_cuda and x.dtype == torch.float32:
+                a = _LatentMLP.apply(x, L["norm"]["scale"], L["norm"]["bias"], L["linear_1"]["kernel"], L["linear_1"]["bias"],
+                                     L["linear_2"]["kernel"], L["linear_2"]["bias"])
+            else:                                                                     # host tensors (tests of the host logic)
+                x = Fnn.layer_norm(x, (x.shape[-1],), L["norm"]["scale"], L["norm"]["bias"], 1e-6)
+                a = _dense(_gelu(_dense(x, L["linear_1"])), L["linear_2"])
         scalar_out = _dense(a, P["readout_scalar"]["layers_0"])
         vec_out = None
         if self.vec_num_out > 0:                                                          # :176-193
@@ -293,6 +406,34 @@ class PonitaODEGen:
             return tuple(None if v is None else v.clone() for v in static_out)
         f.graph = graph
         return f
+
+    def graphed_train(self, params, latents, n):
+        """``n`` training evaluations ``f_k(latents) -> (dp, da, dwindow)``, each replaying its own captured pair of hipGraphs
+        (forward, backward; torch.cuda.make_graphed_callables, one memory pool): an Euler / RK4 roll-out calls every
+        derivative evaluation once per step, and an eager evaluation is ~150 launches and host-bound (2.3-3 ms against 1.3 ms
+        of kernels).  Bitwise equal to ``apply``.  The leaves of ``params`` are read IN PLACE by the graphs and must be
+        leaf tensors that require grad (the trainer keeps persistent ones and copies the current values in); gradients
+        reach them and the input latents through autograd as usual.  Shapes are those of the sample ``latents``."""
+        leaves, build = _flatten_tree(params)
+        p0, a0, w0 = latents
+
+        def fn(p, a, *lv):
+            dp, da, _ = self.apply(build(lv), (p, a, w0))
+            return dp, da
+
+        fresh = lambda t: t.detach().clone().requires_grad_(True)       # own input buffers per capture: a backward may read them
+        samples = tuple((fresh(p0), fresh(a0), *leaves) for _ in range(n))
+        graphed = torch.cuda.make_graphed_callables((fn,) * n, samples, allow_unused_input=True)
+        graphed = graphed if isinstance(graphed, tuple) else (graphed,)
+
+        def wrap(g):
+            def f(z):
+                p, a, w = z
+                dp, da = g(p if p.requires_grad else p.detach().requires_grad_(True),
+                           a if a.requires_grad else a.detach().requires_grad_(True), *leaves)
+                return dp, da, (torch.zeros_like(w) if w is not None else None)
+            return f
+        return [wrap(g) for g in graphed]
 
     def apply(self, params, latents):
         p, a, window = latents

@@ -218,6 +218,11 @@ class MetaSGDPDETrainer:
         self.config, self.nef, self.outer_autodecoder, self.coords, self.seed = config, nef, outer_autodecoder, coords, seed
         self.second_order, self.fd_step = second_order, fd_step
         self.ode_model = ode_model
+        # opt-in: ode / dual train steps replay captured hipGraphs of the derivative evaluations (PonitaODEGen.graphed_train).
+        # Off by default: an isolated evaluation is host-bound and gains (2.4 -> 1.8 ms), but inside a train step the host runs
+        # ahead of the GPU, the eager queue issues kernels back to back, and graph replay's larger kernel-to-kernel gaps make
+        # the 10-frame step SLOWER (30.0 vs 26.4 ms, scripts/bench_ode.py)
+        self.graph_ode_training = bool(getattr(getattr(config, "training", None), "graph_ode_training", False))
         o, m = config.optimizer, config.meta
         self.nef_opt = AdamW(o.learning_rate_enf)                              # after clip_by_global_norm(1.0)
         self.autodecoder_opt = Adam(o.learning_rate_codes)
@@ -371,16 +376,48 @@ class MetaSGDPDETrainer:
                 self._ode_graph = hit
             f = hit[1]
             return solve_latent_ode(lambda z, t: f(z), z0, 0, num_frames - 1, cfg.node.dt, method=cfg.node.method)
+        if graph and torch.is_grad_enabled() and hasattr(self.ode_model, "graphed_train") and z0[1].is_cuda:
+            # training: one captured (forward, backward) pair per derivative evaluation of the roll-out; ``ode_params`` must
+            # be the persistent leaves of _ode_static_leaves (the graphs keep their addresses)
+            leaves = _leaves(ode_params)
+            n_eval = (num_frames - 1) * (4 if cfg.node.method == "rk4" else 1)
+            key = (tuple(id(t) for t in leaves), tuple(None if v is None else tuple(v.shape) for v in z0), n_eval)
+            cache = self.__dict__.setdefault("_ode_train_graphs", {})
+            if key not in cache:
+                if len(cache) >= 4:
+                    cache.clear()
+                cache[key] = (self.ode_model.graphed_train(ode_params, z0, n_eval), leaves)
+            calls = iter(cache[key][0])
+            return solve_latent_ode(lambda z, t: next(calls)(z), z0, 0, num_frames - 1, cfg.node.dt, method=cfg.node.method)
         return solve_latent_ode(lambda z, t: self.ode_model.apply(ode_params, z), z0, 0, num_frames - 1, cfg.node.dt,
                                 method=cfg.node.method)
 
-    def ode_loss(self, nef_params, ode_params, lat, trajectory, point_masks=None, generator=None):
+    def _ode_static_leaves(self, ode_params):
+        """The ODE parameters as PERSISTENT leaf tensors that require grad, holding the current values: captured training
+        evaluations read their parameters by address, the optimiser hands out new tensors every step."""
+        cur = _leaves(ode_params)
+        st = getattr(self, "_ode_static", None)
+        if st is None or len(st) != len(cur) or any(a.shape != b.shape or a.device != b.device for a, b in zip(st, cur)):
+            st = [t.detach().clone().requires_grad_(True) for t in cur]
+            self._ode_static = st
+            self.__dict__.pop("_ode_train_graphs", None)
+        else:
+            with torch.no_grad():
+                torch._foreach_copy_(st, [t.detach() for t in cur])
+        return st
+
+    def _ode_train_leaves(self, ode_params):
+        if self.graph_ode_training and _leaves(ode_params)[0].is_cuda:
+            return self._ode_static_leaves(ode_params), True
+        return [t.detach().requires_grad_(True) for t in _leaves(ode_params)], False
+
+    def ode_loss(self, nef_params, ode_params, lat, trajectory, point_masks=None, generator=None, graph=False):
         """pde_trainer.py:411-481 from the fitted latents on: roll the latents out over the training frames, decode every
         frame (at ``max_num_sampled_points`` random grid points per frame when the grid is larger) and compare.
         ``trajectory`` (B, T, *grid, O);  ``point_masks`` (T, n_s) long, or None to draw them."""
         cfg = self.config
         B, T = trajectory.shape[:2]
-        sol = self.rollout(ode_params, lat, T)
+        sol = self.rollout(ode_params, lat, T, graph=graph)
         p_fl, a_fl, w_fl = (None if v is None else v.reshape(B * T, *v.shape[2:]) for v in sol)
         traj = trajectory.reshape(B, T, -1, trajectory.shape[-1])
         N, n_s = self.coords.shape[0], cfg.training.max_num_sampled_points
@@ -409,9 +446,9 @@ class MetaSGDPDETrainer:
         cfg = self.config
         trajectory = trajectory[:, :cfg.dataset.traj_len_train]                  # pde_trainer.py:421-422
         lat = self._fitted(state, trajectory, masks)
-        leaves = [t.detach().requires_grad_(True) for t in _leaves(state.params["ode_params"])]
+        leaves, graph = self._ode_train_leaves(state.params["ode_params"])
         ode_params = _unflatten(state.params["ode_params"], leaves)
-        loss = self.ode_loss(state.params["nef"], ode_params, lat, trajectory, point_masks, state.rng)
+        loss = self.ode_loss(state.params["nef"], ode_params, lat, trajectory, point_masks, state.rng, graph=graph)
         grads = list(torch.autograd.grad(loss, leaves, allow_unused=True))
         grads = [torch.zeros_like(t) if g is None else g for t, g in zip(leaves, grads)]
         flat = grads + [loss.detach().reshape(1)]
@@ -430,7 +467,7 @@ class MetaSGDPDETrainer:
         cfg = self.config
         trajectory = trajectory[:, :cfg.dataset.traj_len_train]
         coords, img, masks = self._fit_initial_latents(state, trajectory[:, 0], masks)
-        leaves = [t.detach().requires_grad_(True) for t in _leaves(state.params["ode_params"])]
+        leaves, graph = self._ode_train_leaves(state.params["ode_params"])
         ode_params = _unflatten(state.params["ode_params"], leaves)
         if point_masks is None and cfg.training.max_num_sampled_points < self.coords.shape[0]:
             point_masks = torch.stack([torch.randperm(self.coords.shape[0], generator=state.rng)[:cfg.training.max_num_sampled_points]
@@ -440,7 +477,7 @@ class MetaSGDPDETrainer:
         def terminal(weights, lat, keys):
             w = [t.detach().requires_grad_(True) for t in weights]
             lv = {k: lat[k].detach().requires_grad_(True) for k in lat}
-            loss = self.ode_loss(_tree_from_tensors(w), ode_params, lv, trajectory, point_masks)
+            loss = self.ode_loss(_tree_from_tensors(w), ode_params, lv, trajectory, point_masks, graph=graph)
             g = torch.autograd.grad(loss, w + [lv[k] for k in keys] + leaves, allow_unused=True)
             z = lambda t, gi: torch.zeros_like(t) if gi is None else gi
             side["ode"] = [z(t, gi) for t, gi in zip(leaves, g[len(w) + len(keys):])]

@@ -284,12 +284,17 @@ int enf_meta_sgd_update(int nseg, const EnfSgdSegment* segs, float scale, void* 
  * MFMA tiles consumed in registers.  kb element (b,r,s,j) is read at b*Z*Z*J + r*kb_stride_r + s*kb_stride_s + j, so
  * the same entry point gives the gradient w.r.t. the senders:  d a = conv(g, kb with the (r,s) strides swapped, W, NULL).
  * enf_ode_conv_backward_basis:  d kb[b,r,s,:] = W (g[b,r,:] * a[b,s,:])   (B,Z,Z,J).
- * d W = kb^T (g (x) a) over the pair axis is a plain GEMM, left to the caller's BLAS; d bias = sum_{b,r} g.
+ * enf_ode_conv_backward_weight: d W (J,C) = kb^T (g (x) a) over the pair axis, the (B,Z,Z,C) product formed in registers;
+ *   scratch: enf_ode_conv_backward_weight_scratch_bytes(B,Z,J,C) bytes (per-workgroup partials, summed in a fixed order).
+ * d bias = sum_{b,r} g is left to the caller.
  * J, C in {16, 32, 64, 128}; all buffers fp32, contiguous, 16-byte aligned. */
 int enf_ode_conv_forward(int B, int Z, int J, int C, const float* a, const float* kb, int64_t kb_stride_r,
                          int64_t kb_stride_s, const float* W, const float* bias, float* out, void* stream);
 int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const float* a, const float* g, const float* W, float* dkb,
                                 void* stream);
+size_t enf_ode_conv_backward_weight_scratch_bytes(int B, int Z, int J, int C);
+int enf_ode_conv_backward_weight(int B, int Z, int J, int C, const float* a, const float* kb, const float* g, float* dW,
+                                 void* scratch, size_t scratch_bytes, void* stream);
 /* PolynomialFeatures (ponita_ode_g.py:15-26) of the P = B Z^2 pair invariants x (P, I): the Kronecker powers
  * [x, x(x)x, ..., x^(x)(degree+1)] concatenated, F = I + I^2 + ... + I^(degree+1) values per pair (enf_ode_poly_num_features;
  * 340 for I = 4, degree = 3), in the reference's order (each power appends its new factor as the last index).
@@ -297,6 +302,20 @@ int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const float* a, cons
 int enf_ode_poly_num_features(int I, int degree);
 int enf_ode_poly_forward(int64_t P, int I, int degree, const float* x, float* feat, void* stream);
 int enf_ode_poly_backward(int64_t P, int I, int degree, const float* x, const float* dfeat, float* dx, void* stream);
+/* The kernel basis of PonitaGen (ponita_ode_g.py:128-131, 158-160), fused:  kb = gelu(gelu(poly(inv) W1 + b1) W3 + b3)
+ * over the P = B Z^2 pairs, inv (P, I), W1 (F, H1), b1 (H1), W3 (H1, J), b3 (J) as in the reference's parameter tree
+ * (kernel_basis/layers_1, layers_3), kb (P, J); gelu = the tanh form (flax default).  Neither the (P, F) feature tensor nor
+ * the (P, H1) hidden layer touch memory (csrc/enf_ode_basis.hip).  backward: given d kb (P, J) -> d inv (P, I), d W1, d b1,
+ * d W3, d b3 (all OVERWRITTEN; weight gradients are summed in a fixed order: bitwise reproducible).
+ * I in 1..4, degree = 3, H1 in {32, 64, 128} (forward also 256), J in {32, 64, 128} (enf_ode_basis_supported -> 1 / 0);
+ * `scratch`: enf_ode_basis_scratch_bytes(P, I, H1, J, backward) bytes, 16-byte aligned, contents need not be kept. */
+int enf_ode_basis_supported(int I, int degree, int H1, int J, int backward);
+size_t enf_ode_basis_scratch_bytes(int64_t P, int I, int H1, int J, int backward);
+int enf_ode_basis_forward(int64_t P, int I, int degree, int H1, int J, const float* inv, const float* W1, const float* b1,
+                          const float* W3, const float* b3, float* kb, void* scratch, size_t scratch_bytes, void* stream);
+int enf_ode_basis_backward(int64_t P, int I, int degree, int H1, int J, const float* inv, const float* W1, const float* b1,
+                           const float* W3, const float* b3, const float* dkb, float* dinv, float* dW1, float* db1,
+                           float* dW3, float* db3, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Weight gradients of the per-pair chain (enf_backward_weights).  enf_pair_backward_ex plus, in the same
  * call, the gradients of the loss w.r.t. the ten trainable ENF_P_* tensors:

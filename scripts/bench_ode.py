@@ -61,8 +61,19 @@ def fwd_bwd():
 
 
 ms_fb = timed(fwd_bwd)
+# the same evaluation as a captured (forward, backward) hipGraph pair: what the trainer's ode / dual steps replay
+gp, ga = p.clone().requires_grad_(True), a.clone().requires_grad_(True)
+gf = ode.graphed_train(P, (gp, ga, w), 1)[0]
+
+
+def fwd_bwd_graphed():
+    dp, da, _ = gf((gp, ga, w))
+    torch.autograd.grad((dp ** 2).sum() + (da ** 2).sum(), leaves + [gp, ga], allow_unused=True)
+
+
+ms_fb_graph = timed(fwd_bwd_graphed)
 if os.environ.get("ODE_PHASE") == "eval":          # profiling aid: only the derivative evaluation
-    print(json.dumps({"ms_ode_eval_fwd": ms_fwd, "ms_ode_eval_fwd_bwd": ms_fb}))
+    print(json.dumps({"ms_ode_eval_fwd": ms_fwd, "ms_ode_eval_fwd_bwd": ms_fb, "ms_ode_eval_fwd_bwd_graphed": ms_fb_graph}))
     sys.exit(0)
 # the fused convolution alone
 A_, KB, W_, b_ = torch.randn(B, Z, H, device=dev), torch.randn(B, Z, Z, J, device=dev), torch.randn(J, H, device=dev), torch.randn(H, device=dev)
@@ -87,16 +98,20 @@ def step():
     _, state[0] = tr.ode_train_step(state[0], traj)
 
 
-ms_step = timed(step, max(3, iters // 4))
+ms_step_eager = timed(step, max(3, iters // 4))
 if os.environ.get("ODE_PHASE") == "step":          # profiling aid: only the eager train step
-    print(json.dumps({"ms_ode_train_step": ms_step}))
+    print(json.dumps({"ms_ode_train_step_eager": ms_step_eager}))
     sys.exit(0)
+tr.graph_ode_training = True
+ms_step = timed(step, max(3, iters // 4))
+tr.graph_ode_training = False
 with torch.no_grad():
     ms_val = timed(lambda: tr.val_step(state[0], traj), max(3, iters // 4))
 print(json.dumps({"workload": f"ponita ODE, B={B} Z={Z} C={C} hidden={H} basis={J} layers=3 degree=3 (340 features)",
                   "ms_ode_eval_fwd": round(ms_fwd, 4), "ms_ode_eval_fwd_bwd": round(ms_fb, 4),
+                  "ms_ode_eval_fwd_bwd_graphed": round(ms_fb_graph, 4),
                   "pair_evals_per_s_fwd": round(B * Z * Z / ms_fwd * 1e3, 1),
                   "sep_gconv": {"ms": round(ms_conv, 5), "tflops": round(flops / ms_conv / 1e9, 2), "peak_tflops_fp32_mfma": 157.3,
                                 "frac_mfma": round(flops / ms_conv / 1e9 / 157.3, 4), "gbps": round(bytes_ / ms_conv / 1e6, 1),
                                 "frac_hbm": round(bytes_ / ms_conv / 1e6 / 8000, 4)},
-                  "ms_ode_train_step_10_frames": round(ms_step, 3), "ms_val_step_14_frames_full_grid": round(ms_val, 3)}))
+                  "ms_ode_train_step_10_frames": round(ms_step_eager, 3), "ms_ode_train_step_10_frames_graphed_evals": round(ms_step, 3), "ms_val_step_14_frames_full_grid": round(ms_val, 3)}))

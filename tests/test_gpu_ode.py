@@ -55,6 +55,60 @@ def test_poly_features_match_definition(cuda, I, degree):
     assert rel(xd.grad.cpu().double().numpy(), xr.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("I,H1,J,P", [(4, 128, 64, 16 * 64 * 64 // 8), (4, 128, 64, 1000), (3, 64, 64, 777), (1, 32, 32, 130),
+                                      (2, 64, 128, 257), (4, 32, 64, 64), (3, 128, 128, 1500), (4, 64, 32, 5)])
+def test_kernel_basis_fused_matches_definition(cuda, I, H1, J, P):
+    """enf_ode_basis_forward / _backward (csrc/enf_ode_basis.hip) against the definition in fp64: PolynomialFeatures
+    (ponita_ode_g.py:15-26) -> Dense -> gelu -> Dense -> gelu (:128-131, 158-160); values, d inv and the four weight gradients;
+    pair counts that are not multiples of the kernels' tiles."""
+    from enf_pde_amd.fitting.ode_models.ponita_ode_g import kernel_basis
+    g = torch.Generator().manual_seed(I * 1000 + H1 + J + P)
+    F = O.num_poly_features(I, 3)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    x, W1, b1, W3, b3, w = mk(P, I) * 0.7, mk(F, H1) / F ** 0.5, mk(H1) * 0.3, mk(H1, J) / H1 ** 0.5, mk(J) * 0.3, mk(P, J)
+    ref_in = [t.clone().requires_grad_(True) for t in (x, W1, b1, W3, b3)]
+    gelu = lambda t: torch.nn.functional.gelu(t, approximate="tanh")
+    ref = gelu(gelu(OT.poly_features(ref_in[0], 3) @ ref_in[1] + ref_in[2]) @ ref_in[3] + ref_in[4])
+    (ref * w).sum().backward()
+    dev_in = [t.to(cuda, torch.float32).requires_grad_(True) for t in (x, W1, b1, W3, b3)]
+    out = kernel_basis(dev_in[0], 3, {"kernel": dev_in[1], "bias": dev_in[2]}, {"kernel": dev_in[3], "bias": dev_in[4]})
+    assert type(out.grad_fn).__name__ == "_KernelBasisBackward"                     # the fused path, not the fallback
+    (out * w.to(cuda, torch.float32)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(out.detach().cpu().double().numpy(), ref.detach().numpy()) < 2e-6
+    for i, name in enumerate(["inv", "W1", "b1", "W3", "b3"]):
+        assert rel(dev_in[i].grad.cpu().double().numpy(), ref_in[i].grad.numpy()) < 1e-5, name
+    # bitwise reproducible (fixed-order reduction of the workgroup partials)
+    again = [t.detach().clone().requires_grad_(True) for t in dev_in]
+    o2 = kernel_basis(again[0], 3, {"kernel": again[1], "bias": again[2]}, {"kernel": again[3], "bias": again[4]})
+    (o2 * w.to(cuda, torch.float32)).sum().backward()
+    assert torch.equal(o2, out) and all(torch.equal(a.grad, b.grad) for a, b in zip(again, dev_in))
+
+
+def test_kernel_basis_wide_hidden_and_fallbacks(cuda):
+    """hidden 256 (config_shallow_water.yaml's node) is fused for inference and takes the unfused path for training;
+    I > 4 (ball) always does; both agree with the fused / unfused path of a supported shape."""
+    from enf_pde_amd.fitting.ode_models import ponita_ode_g as M
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    for I, H1, J in [(4, 256, 128), (5, 64, 64), (4, 128, 64)]:
+        F = O.num_poly_features(I, 3)
+        x, K1, K3 = mk(300, I) * 0.7, {"kernel": mk(F, H1) / F ** 0.5, "bias": mk(H1) * 0.1}, {"kernel": mk(H1, J) / H1 ** 0.5, "bias": mk(J) * 0.1}
+        with torch.no_grad():
+            fused = M.kernel_basis(x, 3, K1, K3)
+            M.FUSED_BASIS = False
+            try:
+                plain = M.kernel_basis(x, 3, K1, K3)
+            finally:
+                M.FUSED_BASIS = True
+        assert rel(fused.cpu().double().numpy(), plain.cpu().double().numpy()) < 2e-6
+        xg = x.clone().requires_grad_(True)
+        out = M.kernel_basis(xg, 3, K1, K3)
+        assert (type(out.grad_fn).__name__ == "_KernelBasisBackward") == (I <= 4 and H1 <= 128)
+        out.sum().backward()
+        assert torch.isfinite(xg.grad).all()
+
+
 def test_sep_gconv_rejects_unsupported(cuda):
     from enf_pde_amd.fitting.ode_models import sep_gconv
     z = lambda *s: torch.zeros(*s, device=cuda)

@@ -21,10 +21,10 @@ from enf_pde_amd.enf.latents.autodecoder_meta import PositionOrientationFeatureA
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cuda, n_s=32, T_train=3, T_out=2):
+def _setup(cuda, n_s=32, T_train=3, T_out=2, hidden=16, basis=16, method="euler"):
     cfg = make_cfg("rel_pos_periodic", D=64, H=2, C=8, O=1)
     prm = R.init_params(0, cfg, jitter=0.1)
-    ocfg = ode_cfg("rel_pos_periodic", num_hidden=16, basis_dim=16, num_layers=2)
+    ocfg = ode_cfg("rel_pos_periodic", num_hidden=hidden, basis_dim=basis, num_layers=2)
     oprm = O.init_ponita_ode(1, ocfg, latent_dim=8, jitter=0.1, readout_scale=0.02)
     rng = np.random.default_rng(2)
     lin = np.linspace(-1, 1, 8)
@@ -34,7 +34,7 @@ def _setup(cuda, n_s=32, T_train=3, T_out=2):
               meta=NS(learning_rate_meta_sgd=1e-2, num_inner_steps=2, inner_learning_rate_p=0.5, inner_learning_rate_a=2.0,
                       inner_learning_rate_window=0.0, noise_pos_inner_loop=0.0),
               nef=NS(optimize_gaussian_window=False), training=NS(max_num_sampled_points=n_s),
-              node=NS(dt=1, method="euler"), dataset=NS(traj_len_train=T_train, traj_len_out_horizon=T_out))
+              node=NS(dt=1, method=method), dataset=NS(traj_len_train=T_train, traj_len_out_horizon=T_out))
     nef = build_nef(cfg, "f32")
     ode = _model(ocfg, 8)
     t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
@@ -73,6 +73,34 @@ def test_ode_loss_and_gradient_match_oracle(cuda):
         assert rel(v.grad.cpu().double().numpy(), ref_leaves[k].grad.numpy()) < 5e-3, k
     for k in ("p_pos", "a"):
         assert rel(dl[k].grad.cpu().double().numpy(), tl[k].grad.numpy()) < 5e-3, k
+
+
+@pytest.mark.parametrize("method,step", [("euler", "ode_train_step"), ("rk4", "ode_train_step"), ("euler", "dual_train_step")])
+def test_captured_training_evaluations_equal_eager(cuda, method, step):
+    """With ``training.graph_ode_training`` the ode / dual train steps replay one captured (forward, backward) hipGraph pair per
+    derivative evaluation of the roll-out (PonitaODEGen.graphed_train; fused kernel basis inside: hidden 32, basis 32): three consecutive steps -- the optimiser
+    hands out new parameter tensors, the graphs keep reading the trainer's persistent leaves -- give the losses and
+    parameters of the eager path."""
+    runs = []
+    for graphs in (True, False):
+        cfg, prm, ocfg, oprm, coords, traj, conf, tr, state, t = _setup(cuda, hidden=32, basis=32, method=method)
+        tr.graph_ode_training = graphs
+        batch = t(traj)
+        losses = []
+        for i in range(3):
+            mk = torch.stack([torch.randperm(64, generator=torch.Generator().manual_seed(10 + i))[:32] for _ in range(3)], 1).to(cuda)
+            pm = torch.stack([torch.randperm(64, generator=torch.Generator().manual_seed(20 + i))[:32] for _ in range(3)]).to(cuda)
+            loss, state = getattr(tr, step)(state, batch, masks=mk, point_masks=pm)
+            losses.append(float(loss))
+        assert ("_ode_train_graphs" in tr.__dict__) == graphs
+        runs.append((losses, [v.detach().clone() for _, v in _flat(state.params["ode_params"])]))
+    (la, pa), (lb, pb) = runs
+    # (the dual step also moves the nef weights, whose gradient sums atomically: run-to-run differences of a few 1e-6)
+    tol = 1e-6 if step == "ode_train_step" else 5e-5
+    assert np.allclose(la, lb, rtol=tol, atol=0), (la, lb)
+    assert la[0] != la[2]                                                        # the parameters moved
+    for a, b in zip(pa, pb):
+        assert rel(a.cpu().double().numpy(), b.cpu().double().numpy()) < tol * 10
 
 
 def test_ode_train_step_moves_only_the_ode(cuda):
