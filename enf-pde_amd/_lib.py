@@ -19,7 +19,8 @@ EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invarian
            "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_pair_variant", "enf_backward_weights", "enf_backward_weights_scratch_bytes",
            "enf_mse_value_grad",
            "enf_ode_conv_forward", "enf_ode_conv_backward_basis", "enf_ode_conv_backward_weight", "enf_ode_conv_backward_weight_scratch_bytes", "enf_ode_poly_num_features", "enf_ode_poly_forward",
-           "enf_ode_poly_backward", "enf_ode_basis_supported", "enf_ode_basis_scratch_bytes", "enf_ode_basis_forward",
+           "enf_ode_poly_backward", "enf_ode_block_supported", "enf_ode_block_scratch_bytes", "enf_ode_block_forward", "enf_ode_block_backward",
+           "enf_ode_basis_supported", "enf_ode_basis_scratch_bytes", "enf_ode_basis_forward",
            "enf_ode_basis_backward", "enf_relu_mask_bytes", "enf_meta_sgd_update"]
 ENF_NUM_PAIR_TENSORS = 12          # ENF_P_* of include/enf_hip.h
 (ENF_S_EQ, ENF_S_EV, ENF_S_G1, ENF_S_NH, ENF_S_DA1, ENF_S_DA2, ENF_S_DA3, ENF_S_HEAD0) = range(8)
@@ -129,6 +130,11 @@ def _bind(path, test_hooks):
     lib.enf_ode_poly_forward.argtypes = [i64, ci, ci, vp, vp, vp]
     lib.enf_ode_poly_backward.argtypes = [i64, ci, ci, vp, vp, vp, vp]
     lib.enf_ode_basis_supported.argtypes = [ci, ci, ci, ci, ci]
+    lib.enf_ode_block_supported.argtypes = [ci, ci]
+    lib.enf_ode_block_scratch_bytes.restype = sz
+    lib.enf_ode_block_scratch_bytes.argtypes = [i64, ci, ci]
+    lib.enf_ode_block_forward.argtypes = [i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp]
+    lib.enf_ode_block_backward.argtypes = [i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, sz, vp]
     lib.enf_ode_basis_scratch_bytes.restype = sz
     lib.enf_ode_basis_scratch_bytes.argtypes = [i64, ci, ci, ci, ci]
     lib.enf_ode_basis_forward.argtypes = [i64, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]

@@ -230,13 +230,27 @@ def _dense(x, p):
 
 class _LatentMLP(torch.autograd.Function):
     """ConvBlock after the convolution (ponita_ode_g.py:44-48): LayerNorm(eps 1e-6) -> Dense -> gelu -> Dense over the B Z latent
-    rows, with the backward written out: 4 launches forward and 10 backward instead of the ~25 of the op-by-op autograd graph
-    (bias adds fused into the GEMMs, no gradient-buffer fills / accumulations) -- the evaluation is launch-bound."""
+    rows.  Widths the HIP kernels cover (csrc/enf_ode_block.hip: hidden 32 / 64 / 128, widening factor 2): ONE launch forward,
+    two backward.  Other widths: library GEMMs with the backward written out (4 launches forward, 10 backward instead of the
+    ~25 of the op-by-op autograd graph) -- the evaluation is launch-bound."""
+    EPS = 1e-6
 
     @staticmethod
     def forward(ctx, x, gamma, beta, W1, b1, W2, b2):
-        H = x.shape[-1]
-        xn, mean, rstd = torch.native_layer_norm(x, (H,), gamma, beta, 1e-6)
+        H, M = W1.shape
+        lib = _lib.load()
+        ctx.fused = bool(FUSED_BLOCK and x.is_cuda and x.dtype == torch.float32 and lib.enf_ode_block_supported(H, M))
+        if ctx.fused:
+            x2 = x.reshape(-1, H).contiguous()
+            gamma, beta, W1, b1, W2, b2 = (t.contiguous() for t in (gamma, beta, W1, b1, W2, b2))
+            R = x2.shape[0]
+            out, pre = torch.empty_like(x2), torch.empty((R, M), device=x.device, dtype=torch.float32)
+            _lib.launch(x.device, lib.enf_ode_block_forward, R, H, M, _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(W1), _ptr(b1),
+                        _ptr(W2), _ptr(b2), _LatentMLP.EPS, _ptr(out), _ptr(pre), _stream(x.device))
+            ctx.save_for_backward(x2, gamma, beta, W1, W2, pre)
+            ctx.shape = x.shape
+            return out.view(*x.shape[:-1], H)
+        xn, mean, rstd = torch.native_layer_norm(x, (H,), gamma, beta, _LatentMLP.EPS)
         pre = torch.addmm(b1, xn.reshape(-1, H), W1)
         h = Fnn.gelu(pre, approximate="tanh")
         out = torch.addmm(b2, h, W2)
@@ -245,6 +259,19 @@ class _LatentMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fused:
+            lib = _lib.load()
+            x2, gamma, beta, W1, W2, pre = ctx.saved_tensors
+            (R, H), M = x2.shape, W1.shape[1]
+            g2 = g.reshape(R, H).contiguous()
+            dx = torch.empty_like(x2)
+            dpar = torch.empty(2 * H * M + M + 3 * H, device=x2.device, dtype=torch.float32)
+            n = lib.enf_ode_block_scratch_bytes(R, H, M)
+            sc = torch.empty(n // 4, device=x2.device, dtype=torch.float32)
+            _lib.launch(x2.device, lib.enf_ode_block_backward, R, H, M, _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(W1), _ptr(W2),
+                        _ptr(pre), _ptr(g2), _LatentMLP.EPS, _ptr(dx), _ptr(dpar), _ptr(sc), n, _stream(x2.device))
+            dW1, dW2, db1, db2, dgamma, dbeta = torch.split(dpar, [H * M, M * H, M, H, H, H])
+            return dx.view(ctx.shape), dgamma, dbeta, dW1.view(H, M), db1, dW2.view(M, H), db2
         x, mean, rstd, gamma, beta, xn, pre, h, W1, W2 = ctx.saved_tensors
         H = x.shape[-1]
         g2 = g.reshape(-1, g.shape[-1])
@@ -254,6 +281,9 @@ class _LatentMLP(torch.autograd.Function):
         dx, dgamma, dbeta = torch.ops.aten.native_layer_norm_backward((dpre @ W1.t()).view(x.shape), x, (H,), mean, rstd, gamma, beta,
                                                                       [True, True, True])
         return dx, dgamma, dbeta, dW1, db1, dW2, db2
+
+
+FUSED_BLOCK = os.environ.get("ENF_ODE_UNFUSED_BLOCK", "0") != "1"      # diagnostic switch, like FUSED_BASIS
 
 
 def _trunc_normal(gen, shape, std, device):

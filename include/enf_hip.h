@@ -309,6 +309,19 @@ int enf_ode_poly_backward(int64_t P, int I, int degree, const float* x, const fl
  * d W3, d b3 (all OVERWRITTEN; weight gradients are summed in a fixed order: bitwise reproducible).
  * I in 1..4, degree = 3, H1 in {32, 64, 128} (forward also 256), J in {32, 64, 128} (enf_ode_basis_supported -> 1 / 0);
  * `scratch`: enf_ode_basis_scratch_bytes(P, I, H1, J, backward) bytes, 16-byte aligned, contents need not be kept. */
+/* The per-latent half of a ConvBlock (ponita_ode_g.py:44-48), fused:  out = Dense_2(gelu(Dense_1(LayerNorm_eps(x))))  over the
+ * R = B Z latent rows, x (R, H), gamma / beta (H), W1 (H, M), b1 (M), W2 (M, H), b2 (H) as in the reference's tree
+ * (norm/scale, norm/bias, linear_1, linear_2); gelu = the tanh form.  forward also writes pre = LayerNorm(x) W1 + b1 (R, M)
+ * for the backward.  backward: d out g (R, H) -> d x (R, H) and, in ONE buffer of 2 H M + M + 3 H floats (OVERWRITTEN),
+ * d W1 (H, M) | d W2 (M, H) | d b1 (M) | d b2 (H) | d gamma (H) | d beta (H), summed in a fixed order.
+ * H in {32, 64, 128}, M = 2 H (enf_ode_block_supported); scratch: enf_ode_block_scratch_bytes(R, H, M) bytes, 16-byte aligned. */
+int enf_ode_block_supported(int H, int M);
+size_t enf_ode_block_scratch_bytes(int64_t R, int H, int M);
+int enf_ode_block_forward(int64_t R, int H, int M, const float* x, const float* gamma, const float* beta, const float* W1,
+                          const float* b1, const float* W2, const float* b2, float eps, float* out, float* pre, void* stream);
+int enf_ode_block_backward(int64_t R, int H, int M, const float* x, const float* gamma, const float* beta, const float* W1,
+                           const float* W2, const float* pre, const float* g, float eps, float* dx, float* dparams,
+                           void* scratch, size_t scratch_bytes, void* stream);
 int enf_ode_basis_supported(int I, int degree, int H1, int J, int backward);
 size_t enf_ode_basis_scratch_bytes(int64_t P, int I, int H1, int J, int backward);
 int enf_ode_basis_forward(int64_t P, int I, int degree, int H1, int J, const float* inv, const float* W1, const float* b1,

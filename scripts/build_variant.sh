@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; FLAGS=$2
 mkdir -p variants build_variants/$NAME
 SRC=enf-pde_amd/csrc
-for f in enf_api enf_pack enf_loss enf_wz enf_pair_fwd enf_pair_bwd enf_xtd enf_tail enf_debug enf_ode enf_ode_basis; do
+for f in enf_api enf_pack enf_loss enf_wz enf_pair_fwd enf_pair_bwd enf_xtd enf_tail enf_debug enf_ode enf_ode_basis enf_ode_block; do
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unknown-pragmas $FLAGS -c $SRC/$f.hip -o build_variants/$NAME/$f.o ) &
 done
 wait
