@@ -19,7 +19,7 @@ EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invarian
            "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_pair_variant", "enf_backward_weights", "enf_backward_weights_scratch_bytes",
            "enf_mse_value_grad",
            "enf_ode_conv_forward", "enf_ode_conv_backward_basis", "enf_ode_conv_backward_weight", "enf_ode_conv_backward_weight_scratch_bytes", "enf_ode_poly_num_features", "enf_ode_poly_forward",
-           "enf_ode_poly_backward", "enf_ode_block_supported", "enf_ode_block_scratch_bytes", "enf_ode_block_forward", "enf_ode_block_backward",
+           "enf_ode_poly_backward", "enf_ode_vec_readout_forward", "enf_ode_vec_readout_backward", "enf_ode_block_supported", "enf_ode_block_scratch_bytes", "enf_ode_block_forward", "enf_ode_block_backward",
            "enf_ode_basis_supported", "enf_ode_basis_scratch_bytes", "enf_ode_basis_forward",
            "enf_ode_basis_backward", "enf_relu_mask_bytes", "enf_meta_sgd_update"]
 ENF_NUM_PAIR_TENSORS = 12          # ENF_P_* of include/enf_hip.h
@@ -130,6 +130,9 @@ def _bind(path, test_hooks):
     lib.enf_ode_poly_forward.argtypes = [i64, ci, ci, vp, vp, vp]
     lib.enf_ode_poly_backward.argtypes = [i64, ci, ci, vp, vp, vp, vp]
     lib.enf_ode_basis_supported.argtypes = [ci, ci, ci, ci, ci]
+    cf = ctypes.c_float
+    lib.enf_ode_vec_readout_forward.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, cf, cf, vp, vp, vp]
+    lib.enf_ode_vec_readout_backward.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.enf_ode_block_supported.argtypes = [ci, ci]
     lib.enf_ode_block_scratch_bytes.restype = sz
     lib.enf_ode_block_scratch_bytes.argtypes = [i64, ci, ci]

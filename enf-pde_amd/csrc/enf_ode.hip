@@ -418,3 +418,173 @@ extern "C" int enf_ode_poly_backward(int64_t P, int I, int degree, const float* 
   }
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Vector readout of PonitaGen (ponita_ode_g.py:176-193):  out[b,r,:] = mean_s  wgt[b,r,s] * v[b,r,s,:]  with the pair weight
+//     wgt[b,r,s] = inv[b,r,s,:] . Wi + aw[b,s]        (Dense([invariants | a_s]) with one output; aw = a @ W[I:] per latent)
+// and the pair vector v = cr * u[b,r,:] + cs * w[b,s,:]  (relative position: u = w = p, cr = 1, cs = -1; sender orientation:
+// cr = 0, cs = 1).  The op-by-op path spends ~10 launches forward and ~25 backward on (B, Z, Z, .) intermediates; here one
+// launch each way, no atomics: a workgroup owns 64 receivers (4 threads each, senders strided) and, in the backward, the
+// matching 64 senders for the sums over receivers.  d Wi comes out as one partial per workgroup.
+struct OdeVecArgs {
+  const float* inv; const float* aw; const float* u; const float* w; const float* Wi; const float* g;
+  float* out; float* dinv; float* daw; float* du; float* dw; float* dWi_part;
+  int B, Z, I, D; float cr, cs;
+};
+
+template <int I, int D>
+__global__ __launch_bounds__(256) void enf_ode_vec_fwd_kernel(OdeVecArgs A) {
+  const int b = blockIdx.x, r = blockIdx.y * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3, Z = A.Z;
+  const bool ok = r < Z;
+  const int rc = ok ? r : Z - 1;
+  float wi[I], ur[D], acc[D];
+#pragma unroll
+  for (int i = 0; i < I; ++i) wi[i] = A.Wi[i];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { ur[d] = A.cr * A.u[((size_t)b * Z + rc) * D + d]; acc[d] = 0.f; }
+  const float* ip = A.inv + ((size_t)b * Z + rc) * Z * I;
+  for (int s = part; s < Z; s += 4) {
+    float wgt = A.aw[(size_t)b * Z + s];
+#pragma unroll
+    for (int i = 0; i < I; ++i) wgt += ip[(size_t)s * I + i] * wi[i];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] += wgt * (ur[d] + A.cs * A.w[((size_t)b * Z + s) * D + d]);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    acc[d] += __shfl_xor(acc[d], 1, 64);
+    acc[d] += __shfl_xor(acc[d], 2, 64);
+    if (ok && part == 0) A.out[((size_t)b * Z + r) * D + d] = acc[d] / Z;
+  }
+}
+
+template <int I, int D>
+__global__ __launch_bounds__(256) void enf_ode_vec_bwd_kernel(OdeVecArgs A) {
+  __shared__ float red[64][I];
+  const int b = blockIdx.x, t = threadIdx.x >> 2, part = threadIdx.x & 3, Z = A.Z;
+  const int q = blockIdx.y * 64 + t;                    // receiver index in pass 1, sender index in pass 2
+  const bool ok = q < Z;
+  const int qc = ok ? q : Z - 1;
+  const float invZ = 1.f / Z;
+  float wi[I];
+#pragma unroll
+  for (int i = 0; i < I; ++i) wi[i] = A.Wi[i];
+  // ---- pass 1, receiver q: d inv, d u, d Wi
+  {
+    float gr[D], ur[D], dwi[I], sw = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { gr[d] = ok ? A.g[((size_t)b * Z + q) * D + d] * invZ : 0.f; ur[d] = A.cr * A.u[((size_t)b * Z + qc) * D + d]; }
+#pragma unroll
+    for (int i = 0; i < I; ++i) dwi[i] = 0.f;
+    const size_t row = ((size_t)b * Z + qc) * Z;
+    for (int s = part; s < Z; s += 4) {
+      float x[I], wgt = A.aw[(size_t)b * Z + s], dwgt = 0.f;
+#pragma unroll
+      for (int i = 0; i < I; ++i) { x[i] = A.inv[(row + s) * I + i]; wgt += x[i] * wi[i]; }
+#pragma unroll
+      for (int d = 0; d < D; ++d) dwgt += gr[d] * (ur[d] + A.cs * A.w[((size_t)b * Z + s) * D + d]);
+      sw += wgt;
+#pragma unroll
+      for (int i = 0; i < I; ++i) {
+        dwi[i] += dwgt * x[i];
+        if (ok) A.dinv[(row + s) * I + i] = dwgt * wi[i];
+      }
+    }
+    sw += __shfl_xor(sw, 1, 64);
+    sw += __shfl_xor(sw, 2, 64);
+    if (ok && part == 0) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) A.du[((size_t)b * Z + q) * D + d] = A.cr * gr[d] * sw;
+    }
+#pragma unroll
+    for (int i = 0; i < I; ++i) {
+      dwi[i] += __shfl_xor(dwi[i], 1, 64);
+      dwi[i] += __shfl_xor(dwi[i], 2, 64);
+      if (part == 0) red[t][i] = dwi[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < I) {
+      float s = 0.f;
+      for (int k = 0; k < 64; ++k) s += red[k][threadIdx.x];
+      A.dWi_part[((size_t)b * gridDim.y + blockIdx.y) * I + threadIdx.x] = s;
+    }
+  }
+  // ---- pass 2, sender q: d aw, d w (sums over the receivers; wgt and d wgt recomputed)
+  {
+    float ws[D], dws[D], daw = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { ws[d] = A.cs * A.w[((size_t)b * Z + qc) * D + d]; dws[d] = 0.f; }
+    const float awq = A.aw[(size_t)b * Z + qc];
+    for (int r = part; r < Z; r += 4) {
+      float wgt = awq, dwgt = 0.f;
+#pragma unroll
+      for (int i = 0; i < I; ++i) wgt += A.inv[(((size_t)b * Z + r) * Z + qc) * I + i] * wi[i];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const float gd = A.g[((size_t)b * Z + r) * D + d] * invZ;
+        dwgt += gd * (A.cr * A.u[((size_t)b * Z + r) * D + d] + ws[d]);
+        dws[d] += wgt * gd;
+      }
+      daw += dwgt;
+    }
+    daw += __shfl_xor(daw, 1, 64);
+    daw += __shfl_xor(daw, 2, 64);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      dws[d] += __shfl_xor(dws[d], 1, 64);
+      dws[d] += __shfl_xor(dws[d], 2, 64);
+    }
+    if (ok && part == 0) {
+      A.daw[(size_t)b * Z + q] = daw;
+#pragma unroll
+      for (int d = 0; d < D; ++d) A.dw[((size_t)b * Z + q) * D + d] = A.cs * dws[d];
+    }
+  }
+}
+
+static int ode_vec_check(int B, int Z, int I, int D) {
+  if (B <= 0 || Z <= 0 || B > 65535) return ENF_EINVAL;
+  if (I < 1 || I > 6 || D < 2 || D > 3) return ENF_EUNSUPPORTED;
+  return ENF_OK;
+}
+#define ODE_VEC_DISPATCH(KERN)                                                                         \
+  switch (I * 10 + D) {                                                                                \
+    case 12: hipLaunchKernelGGL((KERN<1, 2>), grid, dim3(256), 0, st, A); break;                       \
+    case 13: hipLaunchKernelGGL((KERN<1, 3>), grid, dim3(256), 0, st, A); break;                       \
+    case 22: hipLaunchKernelGGL((KERN<2, 2>), grid, dim3(256), 0, st, A); break;                       \
+    case 23: hipLaunchKernelGGL((KERN<2, 3>), grid, dim3(256), 0, st, A); break;                       \
+    case 32: hipLaunchKernelGGL((KERN<3, 2>), grid, dim3(256), 0, st, A); break;                       \
+    case 33: hipLaunchKernelGGL((KERN<3, 3>), grid, dim3(256), 0, st, A); break;                       \
+    case 42: hipLaunchKernelGGL((KERN<4, 2>), grid, dim3(256), 0, st, A); break;                       \
+    case 43: hipLaunchKernelGGL((KERN<4, 3>), grid, dim3(256), 0, st, A); break;                       \
+    case 52: hipLaunchKernelGGL((KERN<5, 2>), grid, dim3(256), 0, st, A); break;                       \
+    case 53: hipLaunchKernelGGL((KERN<5, 3>), grid, dim3(256), 0, st, A); break;                       \
+    case 62: hipLaunchKernelGGL((KERN<6, 2>), grid, dim3(256), 0, st, A); break;                       \
+    default: hipLaunchKernelGGL((KERN<6, 3>), grid, dim3(256), 0, st, A); break;                       \
+  }
+
+extern "C" int enf_ode_vec_readout_forward(int B, int Z, int I, int D, const float* inv, const float* aw, const float* u,
+                                           const float* w, float cr, float cs, const float* Wi, float* out, void* stream) {
+  int rc = ode_vec_check(B, Z, I, D);
+  if (rc) return rc;
+  if (!inv || !aw || !u || !w || !Wi || !out) return ENF_EINVAL;
+  OdeVecArgs A{inv, aw, u, w, Wi, nullptr, out, nullptr, nullptr, nullptr, nullptr, nullptr, B, Z, I, D, cr, cs};
+  const dim3 grid(B, (Z + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+  ODE_VEC_DISPATCH(enf_ode_vec_fwd_kernel)
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+}
+
+// dWi_part: (B * ceil(Z / 64), I) partial sums, to be added up by the caller (fixed order)
+extern "C" int enf_ode_vec_readout_backward(int B, int Z, int I, int D, const float* inv, const float* aw, const float* u,
+                                            const float* w, float cr, float cs, const float* Wi, const float* g, float* dinv,
+                                            float* daw, float* du, float* dw, float* dWi_part, void* stream) {
+  int rc = ode_vec_check(B, Z, I, D);
+  if (rc) return rc;
+  if (!inv || !aw || !u || !w || !Wi || !g || !dinv || !daw || !du || !dw || !dWi_part) return ENF_EINVAL;
+  OdeVecArgs A{inv, aw, u, w, Wi, g, nullptr, dinv, daw, du, dw, dWi_part, B, Z, I, D, cr, cs};
+  const dim3 grid(B, (Z + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+  ODE_VEC_DISPATCH(enf_ode_vec_bwd_kernel)
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+}

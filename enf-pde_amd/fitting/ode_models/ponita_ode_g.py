@@ -286,6 +286,44 @@ class _LatentMLP(torch.autograd.Function):
 FUSED_BLOCK = os.environ.get("ENF_ODE_UNFUSED_BLOCK", "0") != "1"      # diagnostic switch, like FUSED_BASIS
 
 
+class _VecReadout(torch.autograd.Function):
+    """out[b,r,:] = mean_s (inv[b,r,s,:] . Wi + aw[b,s]) * (cr u[b,r,:] + cs w[b,s,:]): the vector readout (ponita_ode_g.py:176-193)
+    in one HIP launch each way (csrc/enf_ode.hip: enf_ode_vec_readout_*) instead of ~10 + ~25 element-wise / reduction launches."""
+
+    @staticmethod
+    def supported(inv, u):
+        return FUSED_READOUT and inv.is_cuda and inv.dtype == torch.float32 and inv.shape[-1] <= 6 and u.shape[-1] in (2, 3)
+
+    @staticmethod
+    def forward(ctx, inv, aw, u, w, Wi, cr, cs):
+        lib = _lib.load()
+        inv, aw, u, w, Wi = (t.contiguous() for t in (inv, aw, u, w, Wi))
+        B, Z, _, I = inv.shape
+        D = u.shape[-1]
+        out = torch.empty((B, Z, D), device=inv.device, dtype=torch.float32)
+        _lib.launch(inv.device, lib.enf_ode_vec_readout_forward, B, Z, I, D, _ptr(inv), _ptr(aw), _ptr(u), _ptr(w), cr, cs, _ptr(Wi),
+                    _ptr(out), _stream(inv.device))
+        ctx.save_for_backward(inv, aw, u, w, Wi)
+        ctx.c = (cr, cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        inv, aw, u, w, Wi = ctx.saved_tensors
+        B, Z, _, I = inv.shape
+        D = u.shape[-1]
+        g = g.contiguous()
+        dinv, daw, du, dw = torch.empty_like(inv), torch.empty_like(aw), torch.empty_like(u), torch.empty_like(w)
+        part = torch.empty((B * ((Z + 63) // 64), I), device=inv.device, dtype=torch.float32)
+        _lib.launch(inv.device, lib.enf_ode_vec_readout_backward, B, Z, I, D, _ptr(inv), _ptr(aw), _ptr(u), _ptr(w), ctx.c[0], ctx.c[1],
+                    _ptr(Wi), _ptr(g), _ptr(dinv), _ptr(daw), _ptr(du), _ptr(dw), _ptr(part), _stream(inv.device))
+        return dinv, daw, du, dw, part.sum(0), None, None
+
+
+FUSED_READOUT = os.environ.get("ENF_ODE_UNFUSED_READOUT", "0") != "1"      # diagnostic switch, like FUSED_BASIS
+
+
 def _trunc_normal(gen, shape, std, device):
     t = torch.empty(shape, dtype=torch.float32)
     torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=gen)
@@ -372,7 +410,6 @@ class PonitaGen:
         scalar_out = _dense(a, P["readout_scalar"]["layers_0"])
         vec_out = None
         if self.vec_num_out > 0:                                                          # :176-193
-            rel_pos = p[:, :, None, :zp] - p[:, None, :, :zp]
             # Dense([invariants | a_s]) = invariants @ W[:I] + (a @ W[I:]) of the sender, without the (B, Z, Z, I + H) concat
             I = invariants.shape[-1]
 
@@ -381,9 +418,19 @@ class PonitaGen:
                 # weight gradient the same again); a broadcast multiply + sum over I is a few us
                 inv_part = (invariants[..., None] * Wk[:I]).sum(-2) if Wk.shape[1] <= 4 else invariants @ Wk[:I]
                 return inv_part + (a @ Wk[I:])[:, None, :, :]
-            vec_out = (readout(P["readout_vec_rel"]["kernel"]) * rel_pos).mean(-2)
+            fused = P["readout_vec_rel"]["kernel"].shape[1] == 1 and _VecReadout.supported(invariants, p[..., :zp])
+
+            def fused_readout(Wk, u, w, cr, cs):
+                return _VecReadout.apply(invariants, (a @ Wk[I:])[..., 0], u, w, Wk[:I, 0], cr, cs)
+            if fused:
+                vec_out = fused_readout(P["readout_vec_rel"]["kernel"], p[..., :zp], p[..., :zp], 1.0, -1.0)
+            else:
+                vec_out = (readout(P["readout_vec_rel"]["kernel"]) * (p[:, :, None, :zp] - p[:, None, :, :zp])).mean(-2)
             if inv.num_z_ori_dims > 0:
-                vec_out = vec_out + (readout(P["readout_vec_ori"]["kernel"]) * p[:, None, :, zp:]).mean(-2)
+                if fused and p.shape[-1] - zp in (2, 3):
+                    vec_out = vec_out + fused_readout(P["readout_vec_ori"]["kernel"], p[..., zp:], p[..., zp:], 0.0, 1.0)
+                else:
+                    vec_out = vec_out + (readout(P["readout_vec_ori"]["kernel"]) * p[:, None, :, zp:]).mean(-2)
         if self.global_pool:
             scalar_out = scalar_out.mean(1)
             vec_out = vec_out.mean(1) if vec_out is not None else None

@@ -309,6 +309,17 @@ int enf_ode_poly_backward(int64_t P, int I, int degree, const float* x, const fl
  * d W3, d b3 (all OVERWRITTEN; weight gradients are summed in a fixed order: bitwise reproducible).
  * I in 1..4, degree = 3, H1 in {32, 64, 128} (forward also 256), J in {32, 64, 128} (enf_ode_basis_supported -> 1 / 0);
  * `scratch`: enf_ode_basis_scratch_bytes(P, I, H1, J, backward) bytes, 16-byte aligned, contents need not be kept. */
+/* Vector readout of PonitaGen (ponita_ode_g.py:176-193) with one output channel, fused:
+ *     out[b,r,:] = mean_s wgt[b,r,s] * (cr * u[b,r,:] + cs * w[b,s,:]),    wgt[b,r,s] = inv[b,r,s,:] . Wi + aw[b,s]
+ * inv (B,Z,Z,I) the pair invariants, Wi (I) = the readout kernel's rows for the invariants, aw (B,Z) = a @ (its rows for the latent
+ * features), u / w (B,Z,D) receiver / sender vectors (relative position: u = w = p_pos, cr = 1, cs = -1; sender orientation: cr = 0,
+ * cs = 1).  backward: g = d out (B,Z,D) -> d inv, d aw, d u, d w (OVERWRITTEN) and dWi_part (B * ceil(Z/64), I): partial sums of
+ * d Wi, to be added up by the caller.  I <= 6, D in {2, 3}; no atomics. */
+int enf_ode_vec_readout_forward(int B, int Z, int I, int D, const float* inv, const float* aw, const float* u, const float* w,
+                                float cr, float cs, const float* Wi, float* out, void* stream);
+int enf_ode_vec_readout_backward(int B, int Z, int I, int D, const float* inv, const float* aw, const float* u, const float* w,
+                                 float cr, float cs, const float* Wi, const float* g, float* dinv, float* daw, float* du,
+                                 float* dw, float* dWi_part, void* stream);
 /* The per-latent half of a ConvBlock (ponita_ode_g.py:44-48), fused:  out = Dense_2(gelu(Dense_1(LayerNorm_eps(x))))  over the
  * R = B Z latent rows, x (R, H), gamma / beta (H), W1 (H, M), b1 (M), W2 (M, H), b2 (H) as in the reference's tree
  * (norm/scale, norm/bias, linear_1, linear_2); gelu = the tanh form.  forward also writes pre = LayerNorm(x) W1 + b1 (R, M)

@@ -144,6 +144,30 @@ def test_latent_block_fused_matches_definition(cuda, B, Z, H):
     assert torch.equal(o2, outs[0][0]) and all(torch.equal(a.grad, b) for a, b in zip(again, outs[0][1]))
 
 
+@pytest.mark.parametrize("B,Z,I,D,cr,cs", [(16, 64, 4, 2, 1.0, -1.0), (3, 7, 3, 2, 0.0, 1.0), (2, 70, 5, 3, 1.0, -1.0), (1, 130, 1, 2, 1.0, -1.0)])
+def test_vec_readout_fused_matches_definition(cuda, B, Z, I, D, cr, cs):
+    """enf_ode_vec_readout_forward / _backward against the op-by-op definition (ponita_ode_g.py:176-193) in fp64: values and the
+    gradients w.r.t. invariants, per-latent weights, receiver / sender vectors and the invariant rows of the readout kernel."""
+    from enf_pde_amd.fitting.ode_models.ponita_ode_g import _VecReadout
+    g = torch.Generator().manual_seed(B + Z + I)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    inv, aw, u, w_, Wi, ct = mk(B, Z, Z, I), mk(B, Z), mk(B, Z, D), mk(B, Z, D), mk(I), mk(B, Z, D)
+    ref_in = [t.clone().requires_grad_(True) for t in (inv, aw, u, w_, Wi)]
+    wgt = (ref_in[0] * ref_in[4]).sum(-1) + ref_in[1][:, None, :]
+    ref = (wgt[..., None] * (cr * ref_in[2][:, :, None, :] + cs * ref_in[3][:, None, :, :])).mean(-2)
+    (ref * ct).sum().backward()
+    dev_in = [t.to(cuda, torch.float32).requires_grad_(True) for t in (inv, aw, u, w_, Wi)]
+    out = _VecReadout.apply(*dev_in, cr, cs)
+    (out * ct.to(cuda, torch.float32)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(out.detach().cpu().double().numpy(), ref.detach().numpy()) < 2e-6
+    for i, name in enumerate(["inv", "aw", "u", "w", "Wi"]):
+        if name == "u" and cr == 0.0:
+            assert float(dev_in[i].grad.abs().max()) == 0.0
+            continue
+        assert rel(dev_in[i].grad.cpu().double().numpy(), ref_in[i].grad.numpy()) < 1e-5, name
+
+
 def test_sep_gconv_rejects_unsupported(cuda):
     from enf_pde_amd.fitting.ode_models import sep_gconv
     z = lambda *s: torch.zeros(*s, device=cuda)
