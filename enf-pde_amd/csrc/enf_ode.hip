@@ -190,7 +190,8 @@ extern "C" int enf_ode_conv_backward_basis(int B, int Z, int J, int C, const flo
 // at the bench shape, then a split-K library GEMM and two reductions).  The pairs are the MFMA's K index: lane quad q takes
 // senders s0 + 4 q + 0..3 of a 16-sender tile.  A workgroup walks a contiguous share of the (b, r) rows; wave w owns the
 // channel tiles w, w + 4 for every basis tile, accumulates them in registers over the whole share and writes one partial
-// (J, C) per workgroup; enf_ode_sum_partials_kernel adds the partials in a fixed order.
+// (J, C) per workgroup -- followed by its share of d bias[c] = sum_{b,r} g[b,r,c], which costs the kernel one add per row --;
+// enf_ode_sum_partials_kernel adds the partials in a fixed order.
 struct OdeConvDwArgs { const float* a; const float* kb; const float* g; float* part; int B, Z, J, C, rows_per_wg; };
 
 template <int JT, int CK>   // J = 16 JT; CK = channel tiles per wave (C <= 64 CK)
@@ -206,7 +207,9 @@ __global__ __launch_bounds__(256) void enf_ode_conv_dw_kernel(OdeConvDwArgs A) {
   const int row0 = blockIdx.x * A.rows_per_wg, row1 = min(row0 + A.rows_per_wg, A.B * Z);
   const int ST = (Z + 15) / 16, nstep = (row1 - row0) * ST;        // steps = (row, 16-sender tile); operands fetched one step ahead
   f32x4 av[JT], aa[CK], avn[JT], aan[CK];
-  float gv[CK], gvn[CK];
+  float gv[CK], gvn[CK], dbias[CK];                              // d bias[c] = sum over the rows of g[row][c]: rides along
+#pragma unroll
+  for (int k = 0; k < CK; ++k) dbias[k] = 0.f;
   auto fetch = [&](int step, f32x4 (&va)[JT], f32x4 (&vb)[CK], float (&vg)[CK]) {
     const int row = row0 + step / ST, s0 = 16 * (step % ST), b = row / Z;
     const float* kbr = A.kb + (size_t)row * Z * J;
@@ -225,6 +228,10 @@ __global__ __launch_bounds__(256) void enf_ode_conv_dw_kernel(OdeConvDwArgs A) {
   if (nstep > 0) fetch(0, av, aa, gv);
   for (int step = 0; step < nstep; ++step) {
     fetch(step + 1 < nstep ? step + 1 : step, avn, aan, gvn);
+    if (step % ST == 0) {                                        // first sender tile of a row
+#pragma unroll
+      for (int k = 0; k < CK; ++k) dbias[k] += gv[k];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -236,10 +243,11 @@ __global__ __launch_bounds__(256) void enf_ode_conv_dw_kernel(OdeConvDwArgs A) {
 #pragma unroll
     for (int k = 0; k < CK; ++k) { aa[k] = aan[k]; gv[k] = gvn[k]; }
   }
-  float* part = A.part + (size_t)blockIdx.x * J * C;
+  float* part = A.part + (size_t)blockIdx.x * (J * C + C);
 #pragma unroll
   for (int k = 0; k < CK; ++k) {
     if (wave + 4 * k < CT) {
+      if (quad == 0) part[(size_t)J * C + 16 * (wave + 4 * k) + col] = dbias[k];
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -269,7 +277,7 @@ static int ode_dw_wgs(int B, int Z) { return B * Z < 256 ? B * Z : 256; }
 
 extern "C" size_t enf_ode_conv_backward_weight_scratch_bytes(int B, int Z, int J, int C) {
   if (ode_check(B, Z, J, C)) return 0;
-  return (size_t)ode_dw_wgs(B, Z) * J * C * 4;
+  return (size_t)ode_dw_wgs(B, Z) * (J * C + C) * 4;
 }
 
 extern "C" int enf_ode_conv_backward_weight(int B, int Z, int J, int C, const float* a, const float* kb, const float* g,
@@ -285,7 +293,7 @@ extern "C" int enf_ode_conv_backward_weight(int B, int Z, int J, int C, const fl
 #define ODE_DW(JT_, CK_) if (JT == JT_ && CK == CK_) hipLaunchKernelGGL((enf_ode_conv_dw_kernel<JT_, CK_>), dim3(nwg), dim3(256), 0, st, A);
   ODE_DW(1, 1) ODE_DW(2, 1) ODE_DW(4, 1) ODE_DW(8, 1) ODE_DW(1, 2) ODE_DW(2, 2) ODE_DW(4, 2) ODE_DW(8, 2)
 #undef ODE_DW
-  hipLaunchKernelGGL(enf_ode_sum_partials_kernel, dim3((J * C + 31) / 32), dim3(256), 0, st, (const float*)scratch, nwg, J * C, dW);
+  hipLaunchKernelGGL(enf_ode_sum_partials_kernel, dim3((J * C + C + 31) / 32), dim3(256), 0, st, (const float*)scratch, nwg, J * C + C, dW);
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
 

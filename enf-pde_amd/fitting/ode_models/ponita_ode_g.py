@@ -95,12 +95,15 @@ class _SepGconv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dkb = torch.empty_like(kb)
             _lib.launch(a.device, lib.enf_ode_conv_backward_basis, B, Z, J, C, _ptr(a), _ptr(g), _ptr(W), _ptr(dkb), st)
-        if ctx.needs_input_grad[2]:       # d W = kb^T (g (x) a) over the pair axis, g (x) a formed in registers
-            dW = torch.empty_like(W)
+        if ctx.needs_input_grad[2]:       # d W = kb^T (g (x) a) over the pair axis, g (x) a formed in registers; d bias rides along
+            buf = torch.empty(J * C + C, device=a.device, dtype=torch.float32)
             n = lib.enf_ode_conv_backward_weight_scratch_bytes(B, Z, J, C)
             sc = torch.empty(n // 4, device=a.device, dtype=torch.float32)
-            _lib.launch(a.device, lib.enf_ode_conv_backward_weight, B, Z, J, C, _ptr(a), _ptr(kb), _ptr(g), _ptr(dW), _ptr(sc), n, st)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            _lib.launch(a.device, lib.enf_ode_conv_backward_weight, B, Z, J, C, _ptr(a), _ptr(kb), _ptr(g), _ptr(buf), _ptr(sc), n, st)
+            dW = buf[:J * C].view(J, C)
+            if ctx.has_bias and ctx.needs_input_grad[3]:
+                db = buf[J * C:]
+        elif ctx.has_bias and ctx.needs_input_grad[3]:
             db = g.sum((0, 1))
         return da, dkb, dW, db
 

@@ -284,9 +284,9 @@ int enf_meta_sgd_update(int nseg, const EnfSgdSegment* segs, float scale, void* 
  * MFMA tiles consumed in registers.  kb element (b,r,s,j) is read at b*Z*Z*J + r*kb_stride_r + s*kb_stride_s + j, so
  * the same entry point gives the gradient w.r.t. the senders:  d a = conv(g, kb with the (r,s) strides swapped, W, NULL).
  * enf_ode_conv_backward_basis:  d kb[b,r,s,:] = W (g[b,r,:] * a[b,s,:])   (B,Z,Z,J).
- * enf_ode_conv_backward_weight: d W (J,C) = kb^T (g (x) a) over the pair axis, the (B,Z,Z,C) product formed in registers;
+ * enf_ode_conv_backward_weight: d W (J,C) = kb^T (g (x) a) over the pair axis, the (B,Z,Z,C) product formed in registers, and
+ *   d bias (C) = sum_{b,r} g: `dW` is ONE buffer of J*C + C floats, d W followed by d bias;
  *   scratch: enf_ode_conv_backward_weight_scratch_bytes(B,Z,J,C) bytes (per-workgroup partials, summed in a fixed order).
- * d bias = sum_{b,r} g is left to the caller.
  * J, C in {16, 32, 64, 128}; all buffers fp32, contiguous, 16-byte aligned. */
 int enf_ode_conv_forward(int B, int Z, int J, int C, const float* a, const float* kb, int64_t kb_stride_r,
                          int64_t kb_stride_s, const float* W, const float* bias, float* out, void* stream);
