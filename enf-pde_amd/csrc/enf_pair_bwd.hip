@@ -634,10 +634,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       }
 #endif
       ln_stats<NT>(nh, mu1, r1, A.inv_d);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nh[t][i] = (nh[t][i] - mu1) * r1;
+      ln_apply<NT>(nh, mu1, r1);
       make_frags<BF16, KB>(F, nh);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_NH], srow, D, F, quad);
 #if ENF_K3_PARK
@@ -682,10 +679,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         }
 #endif
         ln_stats<NT>(v, mu2, r2, A.inv_d);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[t][i] = (v[t][i] - mu2) * r2;
+        ln_apply<NT>(v, mu2, r2);
 #if ENF_K3_DY2
         // d ybar_h is read twice (a dot product now, the delta below) instead of living in 32 registers in between
         const float* dyrow = A.dybar + qrow * (H * D) + h * D + 4 * quad;
@@ -833,10 +827,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       }
 #endif
       ln_stats<NT>(v, mu2, r2, A.inv_d);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[t][i] = (v[t][i] - mu2) * r2;
+      ln_apply<NT>(v, mu2, r2);
       // d n~ = att * d ybar ;  d att = d ybar . n~ ;  softmax backward with the forward's lse / delta
 #if !ENF_K3_EARLY_DY
       {

@@ -143,10 +143,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
   float mu, rstd;
   ln_stats<NTH>(a, mu, rstd, inv_hd);
   if (SAVE && quad == 0) { act[T::ACT - 2] = mu; act[T::ACT - 1] = rstd; }
-#pragma unroll
-  for (int t = 0; t < NTH; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[t][i] = (a[t][i] - mu) * rstd;
+  ln_apply<NTH>(a, mu, rstd);          // (scalar fmas on purpose: enf_device.h)
   make_frags<BF16, KBH>(FH, a);
 #pragma unroll
   for (int t = 0; t < NTH; ++t) a[t] = rowvec(c_bF1, t, quad);
