@@ -73,6 +73,9 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #ifndef ENF_ANTIPHASE
 #define ENF_ANTIPHASE false
 #endif
+#ifndef ENF_K2_LN_ASM         // the LayerNorm apply as scalar asm fmas (ln_apply, enf_device.h: the form K3 needed).  K2's fmaf loop packed
+#define ENF_K2_LN_ASM 1       // differently and never deviated (scripts/k3_race/fwd_probe.py); the asm form costs nothing (same-box A/B: decode
+#endif                        // 1.238-1.241 vs 1.240-1.250 ms), so K2 avoids the instruction class too
 
 // waves per workgroup: the z-fold variant runs TWO independent 4-wave workgroups per CU (one wave of each
 // per SIMD) so that the SIMD-mates never meet at a barrier: while one computes its MFMA stage the other
@@ -260,11 +263,15 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       gelu_tiles<NT, BF16>(acc);
       float mu, rstd;
       ln_stats<NT>(acc, mu, rstd, A.inv_d);
+#if ENF_K2_LN_ASM
+      ln_apply<NT>(acc, mu, rstd);
+#else
       const float nmr = -mu * rstd;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = fmaf(acc[t][i], rstd, nmr);
+#endif
       make_frags<BF16, KB>(F, acc);   // F = normalised f, shared by all heads' gamma/beta panels
       STAMP(8);
     }
