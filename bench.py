@@ -399,6 +399,56 @@ def meta_leg(c, m, coords, img, device, world, steps=5, warmup=2):
                            if world > 1 else "none at 1 rank (the all-reduce is a no-op)")}
 
 
+# ------------------------------------------------------------------------------------------------- latent ODE (8f-2)
+def ode_leg(c, device, iters=20):
+    """One derivative evaluation of the latent ODE of the config's yaml (PonitaODEGen: hidden 128, basis 64, 3 layers, degree 3) at
+    the bench's latent shape (B signals x Z latents): forward (inference roll-out form: one replayed hipGraph), forward + backward
+    eager and as a captured (forward, backward) graph pair -- SURVEY.md 8f-2, next to the hot path's line (scripts/bench_ode.py has
+    the trainer steps).  Rank 0, one GPU."""
+    from enf_pde_amd.fitting import get_model_pde
+    cfg = model_config(dict(c, rollout=1))
+    _, ode = get_model_pde(cfg)
+    B, Z, C = c["B"], c["Z"], c["C"]
+    g = torch.Generator().manual_seed(0)
+    p = (torch.rand(B, Z, 2, generator=g) * 2 - 1).to(device)
+    a = (1 + 0.1 * torch.randn(B, Z, C, generator=g)).to(device)
+    w = torch.full((B, Z, 1), 0.25, device=device)
+    P = ode.init(0, (p, a, w), device=device)
+    leaves = []
+
+    def collect(t):
+        for v in t.values():
+            collect(v) if isinstance(v, dict) else leaves.append(v.requires_grad_(True))
+    collect(P)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) / iters
+    with torch.no_grad():
+        f = ode.graphed(P, (p, a, w))
+        ms_fwd = timed(lambda: f((p, a, w)))
+    gp, ga = p.clone().requires_grad_(True), a.clone().requires_grad_(True)
+
+    def fb(fn):
+        dp, da, _ = fn((gp, ga, w))
+        torch.autograd.grad((dp ** 2).sum() + (da ** 2).sum(), leaves + [gp, ga], allow_unused=True)
+    ms_fb = timed(lambda: fb(lambda z: ode.apply(P, z)))
+    gt = ode.graphed_train(P, (gp, ga, w), 1)[0]
+    ms_fbg = timed(lambda: fb(gt))
+    return {"workload": f"PonitaODEGen derivative evaluation, {B} signals x {Z} latents ({B * Z * Z} latent pairs), hidden 128, basis 64, 3 layers",
+            "ms_forward_graphed": round(ms_fwd, 4), "ms_forward_backward_eager": round(ms_fb, 4),
+            "ms_forward_backward_graphed": round(ms_fbg, 4), "latent_pairs_per_s_forward": round(B * Z * Z / ms_fwd * 1e3, 1),
+            "dtype": "f32", "note": "fp32 MFMA kernels (csrc/enf_ode*.hip); eager is host-bound, see DESIGN.md 5b"}
+
+
 def _max_over_ranks(dt, device, world):
     if world == 1:
         return dt
@@ -504,6 +554,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-meta", action="store_true", help="skip the outer-step leg")
+    ap.add_argument("--no-ode", action="store_true", help="skip the latent-ODE evaluation leg (config 2, one GPU)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run ONLY the per-kernel legs and print them (for rocprofv3 --kernel-trace --stats: the profile then "
@@ -582,6 +633,11 @@ def main():
                                       note="dominant pair kernel of the step by time; achieved = as-written FLOPs / launch time "
                                            "(backward = 2 x forward, SURVEY.md 8d); executed_frac = MFMA FLOPs issued / time / peak; "
                                            "traffic is not measured in-run (traffic_profile = the committed PMC run, if any)")
+        if world == 1 and not args.no_ode and args.config == 2:
+            try:
+                result["ode_eval"] = ode_leg(c, device)
+            except Exception as e:                       # reported in the line, never hidden: the leg is beside the north-star metric
+                result["ode_eval"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg(c)
         print(json.dumps(result), flush=True)

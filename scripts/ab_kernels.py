@@ -8,7 +8,7 @@ for rnd in range(2):
         env = dict(os.environ)
         if lib != "-":
             env["ENF_HIP_LIB"] = os.path.abspath(lib)
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-meta"], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-meta", "--no-ode"], env=env, capture_output=True, text=True)
         try:
             d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             k = d["roofline_kernels"]
