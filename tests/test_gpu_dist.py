@@ -119,3 +119,20 @@ def test_bench_flags(cuda, flags):
     if "--no-roofline" not in flags:
         assert d["roofline"]["kernel"] in ("enf_pair_fwd_kernel", "enf_pair_bwd_kernel") and d["roofline"]["traffic"] is None
         assert d["meta_step"]["ms_per_step"] > 0
+
+
+def test_bench_default_line_carries_the_ode_leg(cuda):
+    """The headline workload's line also reports the latent-ODE derivative evaluation (`ode_eval`): measured, not an error string."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-meta",
+                        "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    ode = d["ode_eval"]
+    assert "error" not in ode, ode
+    assert 0 < ode["ms_forward_graphed"] < ode["ms_forward_backward_graphed"] and ode["ms_forward_backward_eager"] > 0
+    assert d["config"]["baseline_config"] == 2 and d["value"] > 0
