@@ -618,6 +618,9 @@ static void ob_pack(int I, int H1, int J, const float* W1, const float* W3, floa
   hipLaunchKernelGGL(enf_ode_basis_pack_kernel, dim3((FP * H1 + J * H1 + 255) / 256), dim3(256), 0, st, K);
 }
 
+#ifndef OB_PT_OVERRIDE
+#define OB_PT_OVERRIDE 0   // experiment: pair tiles per wave of the forward kernel (measured at 128 / 64 / I = 4: 1 -> 125 us, 2 -> 84 us, 4 -> 80 us at one wave per SIMD)
+#endif
 #define OB_SHAPES(X, I_) X(I_, 2, 2) X(I_, 4, 2) X(I_, 4, 4) X(I_, 8, 4) X(I_, 8, 8) X(I_, 2, 4) X(I_, 4, 8) X(I_, 2, 8) X(I_, 8, 2)
 #ifdef OB_ONLY_BENCH_SHAPE   // build-time aid: one instantiation
 #define OB_ALL(X) X(4, 8, 4)
@@ -641,7 +644,7 @@ extern "C" int enf_ode_basis_forward(int64_t P, int I, int degree, int H1, int J
   bool done = false;
 #define OB_FWD(I_, H_, J_)                                                                                              \
   if (!done && I == I_ && H1T == H_ && JT == J_) {                                                                      \
-    constexpr int PT = H_ <= 8 ? 2 : 1;                                                                                 \
+    constexpr int PT = OB_PT_OVERRIDE > 0 ? OB_PT_OVERRIDE : (H_ <= 8 ? 2 : 1);                                         \
     hipLaunchKernelGGL((enf_ode_basis_fwd_kernel<I_, H_, J_, PT>), dim3((unsigned)((P + 64 * PT - 1) / (64 * PT))),      \
                        dim3(256), 0, st, A);                                                                            \
     done = true;                                                                                                        \
