@@ -390,8 +390,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // wave of each SIMD).  Round 2 established what this is NOT -- not the LDS-DMA ring (read-back, poison and register-staging
   // builds), not a missed barrier (phase self-check), not a stale scalar cache, not a documented MFMA / trans hazard (all
   // measured, scripts/ubench/) -- and found and removed one real defect of the same symptom (inline-asm relu behind
-  // compiler-scheduled MFMAs, enf_device.h: relu_f).  The remaining effect was never observed with this barrier (0 of ~5000
-  // duplicate-wave checks, tests/test_gpu_backward.py::test_duplicate_waves_agree) and its mechanism is still open: DESIGN.md.
+  // compiler-scheduled MFMAs, enf_device.h: relu_f).  The effect itself turned out to be elsewhere: the SLP-packed LayerNorm apply
+  // (enf_device.h: ln_apply; scripts/k3_race/README.md, "Resolution") -- this barrier had only moved the timing.  It stays in until
+  // its removal is re-validated on its own (it costs ~1 % of K3 at most: same-box A/B 0.504-0.511 vs 0.513-0.517 ms).
   WSTAMP(0);
 #if ENF_K3_ENTRY_BARRIER
   __syncthreads();
