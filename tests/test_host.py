@@ -410,3 +410,31 @@ def test_train_state_checkpoint_keeps_dtypes_and_rng(tmp_path):
     ck.save_tree(str(tmp_path / "t.npz"), {"count": torch.tensor(7), "w": torch.ones(2, dtype=torch.float64)})
     tr = ck.load_tree(str(tmp_path / "t.npz"))
     assert tr["count"].dtype == torch.int64 and tr["w"].dtype == torch.float32
+
+
+def test_pair_kernels_carry_no_packed_add_with_a_negated_high_register_broadcast(tmp_path):
+    """The instruction form behind the "K3 run-to-run deviations" (scripts/k3_race/README.md): `v_pk_add_f32` whose second operand is
+    the HIGH register of a pair broadcast by `op_sel:[0,1]` and negated -- what hipcc's SLP vectoriser makes of a plain
+    `x = (x - mu) * rstd` loop.  The LayerNorm applies go through ln_apply (scalar asm fmas) instead; a new loop of that shape, or
+    a compiler that packs differently, would bring the form back without any parity test noticing (it misbehaves about once
+    per 10^5 executions), so the emitted code of the kernels that had it is checked here."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "enf-pde_amd", "csrc")
+    procs = {}
+    for f in ("enf_pair_bwd", "enf_tail"):
+        out = str(tmp_path / (f + ".s"))
+        procs[f] = (out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unknown-pragmas",
+                                           "--cuda-device-only", "-S", os.path.join(csrc, f + ".hip"), "-o", out],
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    form = re.compile(r"v_pk_add_f32\b.*op_sel:\[0,1\].*neg_lo:\[0,1\]")
+    for f, (out, pr) in procs.items():
+        _, err = pr.communicate(timeout=600)
+        assert pr.returncode == 0, err.decode()[-2000:]
+        text = open(out).read()
+        assert "v_mfma" in text                                             # (really the device code)
+        hits = [ln.strip() for ln in text.splitlines() if form.search(ln)]
+        assert not hits, f"{f}: {len(hits)} x the failing form, e.g. {hits[0]}"
