@@ -556,6 +556,7 @@ def main():
     ap.add_argument("--no-meta", action="store_true", help="skip the outer-step leg")
     ap.add_argument("--no-ode", action="store_true", help="skip the latent-ODE evaluation leg (config 2, one GPU)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs")
+    ap.add_argument("--kernel-iters", type=int, default=20, help="launches per timed per-kernel leg")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run ONLY the per-kernel legs and print them (for rocprofv3 --kernel-trace --stats: the profile then "
                          "holds exactly the launches the legs time, so its per-kernel averages are the legs' launch_ms)")
@@ -581,7 +582,7 @@ def main():
     if args.roofline_only:
         if world != 1:
             raise SystemExit("bench.py --roofline-only runs on one GPU")
-        legs = pair_kernel_rooflines(c, m, device)
+        legs = pair_kernel_rooflines(c, m, device, args.kernel_iters)
         print(json.dumps({"roofline_kernels": {k: v for k, v in legs}, "config": {"workload": f"{c['name']}_b{c['B']}_per_gpu"}}), flush=True)
         return
 
@@ -625,7 +626,7 @@ def main():
         result["split"] = split_leg(c, m, coords, dcoords, img, device)
         result["roofline_step"] = step_roofline(c, ms_per_step, args.precision)
         if not args.no_roofline:
-            legs = pair_kernel_rooflines(c, m, device)
+            legs = pair_kernel_rooflines(c, m, device, args.kernel_iters)
             result["roofline_kernels"] = {k: v for k, v in legs}
             # the dominant kernel = the one the step spends most time in (launch time x launches per step)
             dom = max(legs, key=lambda kv: kv[1]["launch_ms"] * kv[1]["launches_per_step"])

@@ -506,6 +506,7 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
   }
 }
 
+
 template <int BYTES, int NW = NWAVES, bool ANTI = false>
 DEV void first_stage(Pipe& P, char* ring, unsigned panel, int wave, int lane) {
   P.cur = 0;
@@ -537,10 +538,35 @@ template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd
 // seconds, 47 of 47 events with this signature, 0 in 4000 runs of a build without SLP packing).  The asm is opaque to the
 // vectoriser; the leading s_nop covers a transcendental producer (v_rsq_f32) the compiler cannot see being consumed here.
 #ifndef ENF_LN_APPLY_ASM
-#define ENF_LN_APPLY_ASM 1
+#define ENF_LN_APPLY_ASM 2
 #endif
 template <int NT> DEV void ln_apply(f32x4 (&X)[NT], float mu, float rstd) {
-#if ENF_LN_APPLY_ASM
+#if ENF_LN_APPLY_ASM == 2
+  // as below, with the wait states where the hazards are instead of one s_nop per element: ONE in front (rstd comes out of
+  // v_rsq_f32, and a transcendental's result needs a wait state before a VALU read the compiler cannot see), and the two of
+  // VALU -> MFMA operand behind the LAST fma, tied to every tile by data dependence (an asm without operands orders only
+  // against other volatile asm: a compiler-scheduled MFMA reading X -- fp32 mode, where the fragments ARE these registers --
+  // could otherwise be placed above it)
+  float nmr = -mu * rstd;
+  asm volatile("s_nop 0" : "+v"(rstd), "+v"(nmr));
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float y;
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(X[t][i]), "v"(rstd), "v"(nmr));
+      X[t][i] = y;
+    }
+  if constexpr (NT == 8)
+    asm volatile("s_nop 1" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]));
+  else if constexpr (NT == 4)
+    asm volatile("s_nop 1" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]));
+  else {
+    static_assert(NT == 16, "ln_apply: tile counts 4, 8, 16");
+    asm volatile("s_nop 1" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]),
+                 "+v"(X[8]), "+v"(X[9]), "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]));
+  }
+#elif ENF_LN_APPLY_ASM
   const float nmr = -mu * rstd;
 #pragma unroll
   for (int t = 0; t < NT; ++t)

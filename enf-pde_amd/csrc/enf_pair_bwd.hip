@@ -78,14 +78,29 @@
 #ifndef ENF_K3_UF_FUSED       // unfolded heads: the same
 #define ENF_K3_UF_FUSED 1
 #endif
-#ifndef ENF_K3_DY2            // z-fold heads: read d ybar twice instead of keeping it in 32 registers across the head's vector phase
-#define ENF_K3_DY2 0
-#endif
 #ifndef ENF_K3_LA             // z-fold bf16: look-ahead staging (enf_device.h: panel_gemm<.., LA>) -- one stage always in flight
 #define ENF_K3_LA 1
 #endif
 #ifndef ENF_K3_LDSACC
 #define ENF_K3_LDSACC 1
+#endif
+#ifndef ENF_K3_ZF_SPLIT       // z-fold at a full chip: workgroups per latent (query tiles split), co-located on one XCD (launch code below)
+#define ENF_K3_ZF_SPLIT 1
+#endif
+#ifndef ENF_K3_DN_LATE        // z-fold: the d n^ GEMMs run after both heads (their inputs parked as fragments) instead of inside them
+#define ENF_K3_DN_LATE 1
+#endif
+#ifndef ENF_K3_ZF_EARLY_DY    // z-fold heads: d ybar / delta requested before the head's first GEMM stage
+#define ENF_K3_ZF_EARLY_DY 1
+#endif
+#ifndef ENF_K3_INV_SPECIALISED
+#define ENF_K3_INV_SPECIALISED 1
+#endif
+#ifndef ENF_K3_STATIC_PRIO
+#define ENF_K3_STATIC_PRIO 0
+#endif
+#ifndef ENF_K3_XCD_REMAP
+#define ENF_K3_XCD_REMAP 1
 #endif
 
 struct PairBwdArgs {
@@ -100,6 +115,7 @@ struct PairBwdArgs {
   const unsigned* masks; int mask_B;    // STORE only: relu masks to linearise at (ENF_MASK_READ), or nullptr
   int mask_b0;                          // signal index of this launch's b = 0 in the caller's batch (chunked weight-gradient passes)
   int B, N, Z, dx, inv, use_window, nsplit;
+  int xcd_remap;                        // ZF: 1-D grid, the nsplit workgroups of a latent adjacent on one XCD (launch_pair_bwd)
 };
 
 // Debug build only (-DENF_STAMPS): s_memtime stamps of the first tiles of one workgroup (scripts/stamps_k3.py)
@@ -361,9 +377,17 @@ DEV void pair_invariant_bwd(int inv_id, int dx, const QueryPt& q, const f32x4& p
 // head the chain uses the per-latent fold of enf_wz.hip:  a5 = W_zh^T n + c_zh  (one GEMM instead of the gamma/beta
 // GEMM + FiLM + mixer Dense),  d n += W_zh d a5  (one GEMM instead of AM^T and AGB^T), and for d v0 the two flipped
 // products  dv = (AM d a5)^T,  1 + gamma = (Wgamma_h^T n)^T + (1 + bgamma):  512 MFMAs per tile instead of 788.
-template <int D, int H, bool BF16, bool STORE, bool ZF>
+// INV >= 0: the invariant is a compile-time constant (the instantiations the shipped configs run: launch code below).  With the
+// invariant chosen at run time the tile loop carries the switch of pair_invariant / pair_invariant_bwd -- ~2000 instructions of
+// wave-uniform branches whose join points cost spilled registers, and every scratch reload's s_waitcnt vmcnt(0) also waits for
+// the LDS-DMA stage in flight: 4.9 k of a tile's 66 k cycles sat between the last GEMM stage and the next tile's first one.
+template <int D, int H, bool BF16, bool STORE, bool ZF, int INV = -1>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A) {
   static_assert(!(ZF && STORE), "the activation store needs the unfolded chain");
+  static_assert(INV < 0 || INV == ENF_INV_REL_POS_PERIODIC || INV == ENF_INV_LATITUDE_PERIODIC || INV == ENF_INV_POLAR_PERIODIC ||
+                INV == ENF_INV_PONITA, "specialised invariants: two coordinates, no phase");
+  const int inv_id = INV >= 0 ? INV : A.inv;
+  const int dx_ = INV >= 0 ? 2 : A.dx;
   using Cfg = PairCfg<D, BF16>;
   using SM = PairBwdSmem<D, H, BF16>;
   constexpr int KB = Cfg::KB, NT = Cfg::NT, TT = D / 32;
@@ -394,16 +418,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   // (enf_device.h: ln_apply; scripts/k3_race/README.md, "Resolution") -- this barrier had only moved the timing, and it is compiled out
   // now: 21,000 polluted store-probe calls, 10,000 forward / 3,500 training-backward probe iterations and the GPU suite are clean without it.
   WSTAMP(0);
+#if ENF_K3_STATIC_PRIO      // A/B: the second-dispatched half of the workgroup loses every VALU arbitration to its SIMD-mates (T5, static form)
+  if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 #if ENF_K3_ENTRY_BARRIER
   __syncthreads();
 #endif
 
   // this wave's latent: flat (b,z) index; waves past the end keep the barrier cadence only
-  const int bz = ZF ? (int)blockIdx.x : blockIdx.x * NW + wave;
+  // ZF with xcd_remap: workgroup ids are dealt round-robin over the 8 XCDs (id % 8 labels the XCD, MI355X_MICROARCH.md
+  // "Workgroup dispatch"), so the nsplit workgroups that sweep the SAME latent's query tiles take consecutive slots of one
+  // XCD: they stream that latent's W_zh panels at the same time and the XCD's L2 serves all but the first fetch.  Speed only.
+  int bz_ = ZF ? (int)blockIdx.x : blockIdx.x * NW + wave, split_ = blockIdx.y;
+  if constexpr (ZF) {
+    if (A.xcd_remap) {
+      const unsigned k = blockIdx.x >> 3;
+      split_ = (int)(k % (unsigned)A.nsplit);
+      bz_ = (int)((k / (unsigned)A.nsplit) * 8u + (blockIdx.x & 7u));
+    }
+  }
+  const int bz = bz_;
   const bool active = bz < A.B * A.Z;
   const int bzc = active ? bz : A.B * A.Z - 1;
   const int b = bzc / A.Z;
-  const int split = blockIdx.y;
+  const int split = split_;
 
   for (int i = tid; i < D; i += NTHREADS) { c_bq1[i] = G(A.L.bq1)[i]; c_bv1[i] = G(A.L.bv1)[i]; c_bf[i] = G(A.L.bf)[i]; c_bm[i] = G(A.L.bm)[i]; }
   if constexpr (ZF) { for (int i = tid; i < H * D; i += NTHREADS) c_bgb[i] = G(A.L.p_opbg)[i]; }     // 1 + bgamma_h
@@ -434,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   for (int h = 0; h < H; ++h) cz[h] = ltrow[enf_lt_off_c(H, D) + h];
   // ball / ball_lat: the latent's rotation matrix and RFF phases (read from the table row: L1/L2 hits), and the
   // per-column partial sums of their gradients
-  const bool has_ph = SM::EXT_OK && enf_inv_has_phase(A.inv);
+  const bool has_ph = INV < 0 && SM::EXT_OK && enf_inv_has_phase(inv_id);
   const float* ext = ltrow + enf_lt_off_ext(H, D);
   const float* phq = has_ph ? ltrow + enf_lt_off_phq(H, D) : nullptr;
   const float* phv = has_ph ? ltrow + enf_lt_off_phv(H, D) : nullptr;
@@ -531,12 +569,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     float t_lse[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) t_lse[h] = pf_lse[h];
-    const QueryPt q = make_query(pf_x[0], pf_x[1], pf_x[2], A.inv);
+    const QueryPt q = make_query(pf_x[0], pf_x[1], pf_x[2], inv_id);
 #else
-    const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
+    const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * dx_, dx_, inv_id);
 #endif
     float inv[4], win;
-    pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, ext);
+    pair_invariant<BF16>(inv_id, dx_, q, pz, wcoef, A.use_window, inv, win, ext);
     const size_t srow = (size_t)bzc * A.N + n;        // row of the materialised activations (STORE)
     const bool swrite = STORE && nvalid && active;
 
@@ -604,7 +642,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       if (STORE && A.masks) relu_mask = maskv;
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
-      if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a3, F, P, ring, pF, LA ? STAGE_RS2 | (unsigned)PANEL_DD : STAGE_RS2, true, lane, c_bf);
+      if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a3, F, P, ring, pF, LA ? (ENF_K3_DN_LATE ? gM : STAGE_RS2 | (unsigned)PANEL_DD) : STAGE_RS2, true, lane, c_bf);
       else panel_gemm<KB, NT, BF16, ST_GB, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, pGB, true, lane, c_bf);
 #if ENF_K3_A3_FUSED
       // nh = gelu(a3), a3 <- gelu'(a3) from one exp + rcp per element (one tile at a time, as in the heads); the backward
@@ -644,16 +682,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     }
     BSTAMP(2);
     f32x4 dnh[NT];                       // d n^ accumulated over heads
+    constexpr bool DNL = ZF && ENF_K3_DN_LATE != 0;    // z-fold: d n^ = sum_h W_zh d a5_h is taken AFTER the heads, from their parked d a5
+    if constexpr (!DNL) {                              // fragments (16 registers per head instead of the 32 of a running sum)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) dnh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT; ++t) dnh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     if constexpr (ZF) {
+      Frags<BF16, KB> FAh[DNL ? H : 1];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const unsigned wzf = STAGE_RS2 | (unsigned)(h * 2 * PANEL_DD), wzb = wzf + PANEL_DD;
         // ---- a5 = W_zh^T n + c_zh
         f32x4 a5[NT], v[NT];
-        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a5, F, P, ring, wzf, LA ? gM : wzb, true, lane, zv + H * D + h * D);
+#if ENF_K3_ZF_EARLY_DY
+        // this head's d ybar row and delta are requested BEFORE the GEMM stage: the L2 round trip runs under its MFMAs and the gelu
+        // instead of in front of the dot products that consume it (32 registers that are free while d n^ is taken after the heads)
+        f32x4 dy[NT];
+        {
+          const float* dyrow = A.dybar + qrow * (H * D) + h * D + 4 * quad;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t);
+        }
+        const float delta_h = K3_DELTA(h);
+#endif
+        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a5, F, P, ring, wzf, DNL ? (LA ? pWG + h * PANEL_DD : gM) : (LA ? gM : wzb), true, lane, zv + H * D + h * D);
         BSTAMP(4 + 6 * h);
         float mu2, r2;
 #if ENF_K3_ZF_FUSED
@@ -681,69 +734,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #endif
         ln_stats<NT>(v, mu2, r2, A.inv_d);
         ln_apply<NT>(v, mu2, r2);
-#if ENF_K3_DY2
-        // d ybar_h is read twice (a dot product now, the delta below) instead of living in 32 registers in between
-        const float* dyrow = A.dybar + qrow * (H * D) + h * D + 4 * quad;
         float s0 = 0.f, sd = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const f32x4 d = *reinterpret_cast<const f32x4*>(dyrow + 16 * t);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { s0 = fmaf(d[i], v[t][i], s0); sd += d[i]; }
-        }
-#else
+#if !ENF_K3_ZF_EARLY_DY
         f32x4 dy[NT];
-        float s0 = 0.f, sd = 0.f;
+        const float delta_h = K3_DELTA(h);
         {
           const float* dyrow = A.dybar + qrow * (H * D) + h * D + 4 * quad;
 #pragma unroll
           for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t);
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { s0 = fmaf(dy[t][i], v[t][i], s0); sd += dy[t][i]; }
         }
 #endif
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { s0 = fmaf(dy[t][i], v[t][i], s0); sd += dy[t][i]; }
         const float datt = xquad_sum(s0);
-        dlogit[h] = nvalid ? att[h] * (datt - K3_DELTA(h)) : 0.f;
+        dlogit[h] = nvalid ? att[h] * (datt - delta_h) : 0.f;
         const float ah = nvalid ? att[h] : 0.f;
         // LayerNorm backward of the weighted cotangent ah * dy: its two means follow from the sums above,
         // mean(ah dy) = ah mean(dy),  mean(ah dy v) = ah datt / D
         const float m1 = ah * xquad_sum(sd) * A.inv_d, m2 = ah * datt * A.inv_d;
-#if ENF_K3_DY2
-        f32x4 dy[NT];
-        {
-          const float* dyrow2 = dyrow;
-          asm volatile("" : "+v"(dyrow2));          // a second read, not a value kept alive
+        {     // rstd folded into the three per-column scalars: two FMAs and the gelu' product per element
+          const float ahr = ah * r2, m1r = m1 * r2, nm2r = -m2 * r2;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             K3_OPAQUE(a5[t]);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dyrow2 + 16 * t);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              dy[t][i] = r2 * (fmaf(ah, d[i], -m1) - v[t][i] * m2) * (ENF_K3_ZF_FUSED ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
+              dy[t][i] = fmaf(nm2r, v[t][i], fmaf(ahr, dy[t][i], -m1r)) * (ENF_K3_ZF_FUSED ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
           }
         }
-#else
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          K3_OPAQUE(a5[t]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            dy[t][i] = r2 * (fmaf(ah, dy[t][i], -m1) - v[t][i] * m2) * (ENF_K3_ZF_FUSED ? a5[t][i] : gelu_grad_f(a5[t][i]));   // d a5
-        }
-#endif
         BSTAMP(5 + 6 * h);
-        Frags<BF16, KB> FA;
+        Frags<BF16, KB>& FA = FAh[DNL ? h : 0];
         make_frags<BF16, KB>(FA, dy);
         // ---- d n += W_zh d a5
-        panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ACC, LA>(dnh, FA, P, ring, wzb, LA ? pWG + h * PANEL_DD : gM, true, lane);
+        if constexpr (!DNL) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ACC, LA>(dnh, FA, P, ring, wzb, LA ? pWG + h * PANEL_DD : gM, true, lane);
         // ---- d v0 += sum_n dv (1 + gamma), both as flipped products (rows = queries)
         f32x4 dvf[NT];
         {
           f32x4 none[1];
-          const unsigned nxt = h + 1 < H ? wzf + 2 * PANEL_DD : gF;          // the stage after this head's last one ...
-          const unsigned nxt2 = h + 1 < H ? wzb + 2 * PANEL_DD : gV1;        // ... and the one after that
+          const unsigned wzb0 = STAGE_RS2 | (unsigned)PANEL_DD;               // head 0's backward-orientation panel
+          // the stage after this head's last one, and the one after that
+          const unsigned nxt = DNL ? (h + 1 < H ? wzf + 2 * PANEL_DD : wzb0) : (h + 1 < H ? wzf + 2 * PANEL_DD : gF);
+          const unsigned nxt2 = DNL ? (h + 1 < H ? gM : (H > 1 ? wzb0 + 2 * PANEL_DD : gF)) : (h + 1 < H ? wzb + 2 * PANEL_DD : gV1);
           panel_gemm_flip<KB, NT, BF16, ST_DD, NW, false, INIT_ZERO, LA>(
               none, FA, P, ring, gM, LA ? nxt : pWG + h * PANEL_DD, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
               [&](int mt, const f32x4& af) { dvf[mt] = af; });
@@ -762,6 +795,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #endif
         }
         BSTAMP(6 + 6 * h);
+      }
+      if constexpr (DNL) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const unsigned wzb = (STAGE_RS2 | (unsigned)(h * 2 * PANEL_DD)) + PANEL_DD;
+          const unsigned after = h + 1 < H ? wzb + 2 * PANEL_DD : gF;                                   // next stage
+          const unsigned after2 = h + 2 < H ? wzb + 4 * PANEL_DD : (h + 2 == H ? gF : gV1);              // the one after that
+          if (h == 0) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(dnh, FAh[h], P, ring, wzb, LA ? after2 : after, true, lane);
+          else panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ACC, LA>(dnh, FAh[h], P, ring, wzb, LA ? after2 : after, true, lane);
+        }
       }
     } else
 #pragma unroll
@@ -939,6 +982,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int i = 0; i < 4; ++i) { s1 += dnh[t][i]; s2 = fmaf(dnh[t][i], nht[i], s2); }
       }
       const float m1 = xquad_sum(s1) * A.inv_d, m2 = xquad_sum(s2) * A.inv_d;
+      const float m1r = m1 * r1, nm2r = -m2 * r1;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #if ENF_K3_PARK
@@ -949,7 +993,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         const f32x4 nht = nh[t], a3t = a3[t];
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dnh[t][i] = r1 * (dnh[t][i] - m1 - nht[i] * m2) * ((ENF_K3_FUSED_GELU || ENF_K3_A3_FUSED) ? a3t[i] : gelu_grad_f(a3t[i]));   // d a3
+        for (int i = 0; i < 4; ++i)
+          dnh[t][i] = fmaf(nm2r, nht[i], fmaf(r1, dnh[t][i], -m1r)) * ((ENF_K3_FUSED_GELU || ENF_K3_A3_FUSED) ? a3t[i] : gelu_grad_f(a3t[i]));   // d a3
         K3_SCHED_FENCE();
       }
       make_frags<BF16, KB>(F, dnh);
@@ -1058,18 +1103,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       float* dxp = A.dxq ? dxv : nullptr;
       if (has_ph) {
         float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, dR, dxp, ext);
-        if (A.inv == ENF_INV_BALL) {
+        pair_invariant_bwd<BF16>(inv_id, dx_, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, dR, dxp, ext);
+        if (inv_id == ENF_INV_BALL) {
 #pragma unroll
           for (int k = 0; k < 9; ++k) eacc[k * 16] += dR[k];
         }
       } else
-      pair_invariant_bwd<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, nullptr, dxp);
+      pair_invariant_bwd<BF16>(inv_id, dx_, q, pz, wcoef, A.use_window, inv, win, dinv, dwin, dpose, dwc, nullptr, dxp);
       if (A.dxq && nvalid && active) {          // every latent's wave adds its share to the query's gradient
-        float* o = A.dxq + ((size_t)b * A.N + n) * A.dx;
+        float* o = A.dxq + ((size_t)b * A.N + n) * dx_;
         atomicAdd(o, dxv[0]);
-        if (A.dx > 1) atomicAdd(o + 1, dxv[1]);
-        if (A.dx > 2) atomicAdd(o + 2, dxv[2]);
+        if (dx_ > 1) atomicAdd(o + 1, dxv[1]);
+        if (dx_ > 2) atomicAdd(o + 2, dxv[2]);
       }
     } else if (has_ph && quad == 1) { eacc[9 * 16] += dlat[0]; eacc[10 * 16] += dlat[1]; }
   }
@@ -1155,13 +1200,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
   WSTAMP(3);
 }
 
-template <int D, int H, bool BF16, bool STORE, bool ZF>
+template <int D, int H, bool BF16, bool STORE, bool ZF, int INV = -1>
 static int launch_pair_bwd(const PairBwdArgs& A, hipStream_t st) {
   using SM = PairBwdSmem<D, H, BF16>;
-  auto kern = enf_pair_bwd_kernel<D, H, BF16, STORE, ZF>;
+  auto kern = enf_pair_bwd_kernel<D, H, BF16, STORE, ZF, INV>;
   static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
   if (!enf_lds_attr(reinterpret_cast<const void*>(kern), SM::TOTAL, attr_done)) return ENF_ELAUNCH;
   dim3 grid(ZF ? A.B * A.Z : (A.B * A.Z + NWAVES - 1) / NWAVES, A.nsplit);
+  if (ZF && A.xcd_remap) grid = dim3(A.B * A.Z * A.nsplit, 1);
   hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SM::TOTAL, st, A);
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
@@ -1182,7 +1228,16 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
   const int wgs = zf ? m.B * m.Z : (m.B * m.Z + NWAVES - 1) / NWAVES, ntiles = (m.N + 15) / 16;
   int ns = 1;
   while (wgs * ns < 256 && ns * 2 <= ntiles) ns *= 2;
+#ifdef ENF_K3_ZF_NSPLIT      // A/B builds: force the z-fold split
+  if (zf) { ns = ENF_K3_ZF_NSPLIT; while (ns > 1 && ns > ntiles) ns /= 2; }
+#else
+  // z-fold, chip already full: split each latent's sweep over ENF_K3_ZF_SPLIT workgroups placed on one XCD, so that the XCD's
+  // resident workgroups stream 32 / split latents' panels (128 KB each at D = 128, H = 2) instead of 32 -- they then stay in
+  // the 4 MB L2 across the sweep steps instead of coming from HBM every step
+  if (zf && ns == 1 && wgs % 8 == 0 && wgs >= 256) { ns = ENF_K3_ZF_SPLIT; while (ns > 1 && ns * 8 > ntiles) ns /= 2; }
+#endif
   A.nsplit = ns;
+  A.xcd_remap = zf && ns > 1 && wgs % 8 == 0 && ENF_K3_XCD_REMAP;
   if (store)
     for (int i = 0; i < ENF_NUM_STORE(m.H); ++i) A.store[i] = store[i];
 #define ENF_CASE(DD, HH)                                                                   \
@@ -1191,6 +1246,18 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
     if (zf) return m.bf16 ? launch_pair_bwd<DD, HH, true, false, true>(A, st) : launch_pair_bwd<DD, HH, false, false, true>(A, st);    \
     return m.bf16 ? launch_pair_bwd<DD, HH, true, false, false>(A, st) : launch_pair_bwd<DD, HH, false, false, false>(A, st);         \
   }
+#if ENF_K3_INV_SPECIALISED
+  // the z-fold bf16 kernels of the shipped configs with the invariant as a compile-time constant (configs 2, 4, 5:
+  // rel_pos_periodic; config 3: latitude_periodic and the SO(3) polar_periodic; config 1: ponita at num_hidden 64)
+  if (zf && m.bf16 && m.dx == 2) {
+    if (m.D == 128 && m.H == 2) {
+      if (m.inv == ENF_INV_REL_POS_PERIODIC) return launch_pair_bwd<128, 2, true, false, true, ENF_INV_REL_POS_PERIODIC>(A, st);
+      if (m.inv == ENF_INV_LATITUDE_PERIODIC) return launch_pair_bwd<128, 2, true, false, true, ENF_INV_LATITUDE_PERIODIC>(A, st);
+      if (m.inv == ENF_INV_POLAR_PERIODIC) return launch_pair_bwd<128, 2, true, false, true, ENF_INV_POLAR_PERIODIC>(A, st);
+    }
+    if (m.D == 64 && m.H == 2 && m.inv == ENF_INV_PONITA) return launch_pair_bwd<64, 2, true, false, true, ENF_INV_PONITA>(A, st);
+  }
+#endif
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)

@@ -45,7 +45,7 @@ def emit(KB, MTS, NBUF, init):
         if i + NBUF < n:
             L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i + NBUF])}")
     L.append(f"s_nop {TAIL_NOPS}")
-    body = "\n".join(f'      "{x}\\n\\t"' for x in L)
+    body = "      ENF_ASM_PRIO_ON\n" + "\n".join(f'      "{x}\\n\\t"' for x in L[:-1]) + "\n      ENF_ASM_PRIO_OFF\n" + f'      "{L[-1]}\\n\\t"'
     outs = ", ".join(_acc_ops(MTS, init) + [f'[s{j}] "=&v"(s{j})' for j in range(NBUF)])
     ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'] + (['[bias] "v"(bias_addr)'] if init == "bias" else []))
     name = {"acc": "run", "zero": "run_zero", "bias": "run_bias"}[init]
@@ -83,7 +83,7 @@ def emit_both(KB, MTS, NBUF, mask, name, init="acc"):
         if i + NBUF < n:
             L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i + NBUF])}")
     L.append(f"s_nop {TAIL_NOPS}")
-    body = "\n".join(f'      "{x}\\n\\t"' for x in L)
+    body = "      ENF_ASM_PRIO_ON\n" + "\n".join(f'      "{x}\\n\\t"' for x in L[:-1]) + "\n      ENF_ASM_PRIO_OFF\n" + f'      "{L[-1]}\\n\\t"'
     outs = ", ".join(_acc_ops(MTS, init) + [f'[f{j}] "+v"(af[{j}])' for j in range(len(fl))] +
                      [f'[s{j}] "=&v"(s{j})' for j in range(NBUF)])
     ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'] + (['[bias] "v"(bias_addr)'] if init == "bias" else []))
@@ -118,7 +118,7 @@ def emit_flip(KB, MTS, NBUF, init):
         if i + NBUF < n:
             L.append(f"ds_read_b128 %[s{i % NBUF}], %[addr] offset:{off(*order[i + NBUF])}")
     L.append(f"s_nop {TAIL_NOPS}")
-    body = "\n".join(f'      "{x}\\n\\t"' for x in L)
+    body = "      ENF_ASM_PRIO_ON\n" + "\n".join(f'      "{x}\\n\\t"' for x in L[:-1]) + "\n      ENF_ASM_PRIO_OFF\n" + f'      "{L[-1]}\\n\\t"'
     outs = ", ".join(_acc_ops(MTS, init) + [f'[s{j}] "=&v"(s{j})' for j in range(NBUF)])
     ins = ", ".join([f'[b{k}] "v"(B[{k}])' for k in range(KB)] + ['[addr] "v"(lds_addr)'])
     name = {"acc": "run_flip", "zero": "run_flip_zero"}[init]
@@ -139,6 +139,10 @@ BOTH = {(4, 8): [(0xFF, "run_both", 8), (0x33, "run_gb", 8)], (2, 4): [(0xF, "ru
 def main(path):
     # LITE = true: half the fragment registers in flight (4), for kernels short of registers
     out = ["// GENERATED by tools/gen_gemm_asm.py -- do not edit.", "#pragma once", "",
+           "// ENF_ASM_PRIO=1 (A/B builds): s_setprio 1 over a stage's fragment reads and MFMAs, back to 0 before its tail wait states",
+           "#ifndef ENF_ASM_PRIO", "#define ENF_ASM_PRIO 0", "#endif", "#if ENF_ASM_PRIO",
+           '#define ENF_ASM_PRIO_ON "s_setprio 1\\n\\t"', '#define ENF_ASM_PRIO_OFF "s_setprio 0\\n\\t"', "#else",
+           '#define ENF_ASM_PRIO_ON', '#define ENF_ASM_PRIO_OFF', "#endif", "",
            "template <int KB, int MTS, bool LITE = false> struct GemmStageAsm { static constexpr bool available = false; };", ""]
     for lite in (False, True):
         for KB, MTS, NBUF in SHAPES:

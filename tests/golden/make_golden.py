@@ -3,7 +3,7 @@ autograd gradients, one inner-loop trace).  The reference itself cannot be execu
 absent), so these vectors pin the ORACLE (regression) and give the HIP path a fixed target; they do
 not pin the oracle to the reference ("parity unpinned", oracle/enf_ref_np.py).
 
-    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py [case ...]   # rewrites tests/golden/*.npz (all, or the named decoder cases)
 """
 import os
 import sys
@@ -28,6 +28,9 @@ CASES = {
     "cfg2_rel_pos_periodic": (dict(invariant="rel_pos_periodic", D=128, H=2, C=16, O=1), 2, 64, 64, 15, False),
     "tiny_ball": (dict(invariant="ball", D=64, H=2, C=8, O=1, freq=(0.2, 0.5)), 2, 9, 5, 16, False),          # config_ihc.yaml's invariant
     "tiny_ball_lat": (dict(invariant="ball_lat", D=64, H=1, C=8, O=2, freq=(0.2, 0.5)), 2, 7, 4, 17, False),
+    # BASELINE config 3's decoder (config_shallow_water.yaml:39-55: latitude_periodic, 128 latents, latent_dim 32, 3 fields) WITH its
+    # weights: the test loads them from the fixture, so it does not depend on init_params' random stream
+    "cfg3_latitude_periodic": (dict(invariant="latitude_periodic", D=128, H=2, C=32, O=3, freq=(0.05, 0.2)), 1, 48, 128, 18, True),
 }
 
 
@@ -41,10 +44,31 @@ def flatten(tree, prefix=""):
     return out
 
 
+def round_f32(tree):
+    """the tree with every leaf rounded to fp32 (what a fixture stores), still as float64 arrays"""
+    return {k: round_f32(v) if isinstance(v, dict) else np.asarray(v, np.float32).astype(np.float64) for k, v in tree.items()}
+
+
+def unflatten(g, prefix="W/"):
+    """{'params': tree} from a fixture's 'W/a/b/c' entries (float64)"""
+    tree = {}
+    for key in g.files if hasattr(g, "files") else g:
+        if not key.startswith(prefix):
+            continue
+        d = tree
+        parts = key[len(prefix):].split("/")
+        for part in parts[:-1]:
+            d = d.setdefault(part, {})
+        d[parts[-1]] = np.asarray(g[key], np.float64)
+    return {"params": tree} if tree else None
+
+
 def make_case(name):
     kw, B, N, Z, seed, store_w = CASES[name]
     cfg = make_cfg(**kw)
     prm = R.init_params(seed, cfg, jitter=0.1)
+    if store_w and name != "tiny_rel_pos_periodic":      # (that first fixture keeps its fp64-weight outputs: regenerating is bit-stable)
+        prm = {"params": round_f32(prm["params"])}       # outputs below belong to exactly the weights stored
     x, p, a, s = make_inputs(cfg, B, N, Z, seed + 100)
     w = np.random.default_rng(seed + 200).standard_normal((B, N, cfg["num_out"]))
     out = R.nef_apply(prm, cfg, x, p, a, s)
@@ -58,8 +82,6 @@ def make_case(name):
     if store_w:
         for k, v in flatten(prm["params"]).items():
             rec["W/" + k] = v.astype(np.float32)
-        # outputs for the fp32-rounded weights actually stored
-        prm32 = R.init_params(seed, cfg, jitter=0.1)
     return cfg, rec
 
 
@@ -157,14 +179,19 @@ def make_ode_case(name):
 
 
 if __name__ == "__main__":
-    for name in ODE_CASES:
+    for name in ([] if sys.argv[1:] else ODE_CASES):
         cfg, rec = make_ode_case(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
         print(name, {k: v.shape for k, v in rec.items() if hasattr(v, "shape")})
+    only = sys.argv[1:]
     for name in CASES:
+        if only and name not in only:
+            continue
         cfg, rec = make_case(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
         print(name, {k: v.shape for k, v in rec.items() if hasattr(v, "shape") and not k.startswith("W/")})
+    if sys.argv[1:]:
+        sys.exit(0)
     np.savez_compressed(os.path.join(HERE, "inner_loop_ponita.npz"), **make_inner_loop())
     print("inner_loop_ponita written")
     np.savez_compressed(os.path.join(HERE, "config1_trace.npz"), **make_config1_trace())

@@ -74,6 +74,36 @@ def test_backward_shapes(cuda, D, H, C, O, Z, N, precision):
     check(cuda, cfg, B=3, N=N, Z=Z, precision=precision, seed=D + Z)
 
 
+_FULL_REF = {}
+
+
+def _full_size_case(invariant, C, O, Z, N, seed):
+    """oracle gradients of one full-size case, computed once per session (fp64 autograd over N * Z pairs: seconds)"""
+    key = (invariant, C, O, Z, N, seed)
+    if key not in _FULL_REF:
+        cfg = make_cfg(invariant, D=128, H=2, C=C, O=O, freq=(0.05, 0.2))
+        prm = R.init_params(seed, cfg, jitter=0.1)
+        x, p, a, s = make_inputs(cfg, 1, N, Z, seed + 1)
+        w = np.random.default_rng(seed + 2).standard_normal((1, N, O))
+        _FULL_REF[key] = (cfg, prm, (x, p, a, s, w), ref_grads(prm, cfg, x, p, a, s, w))
+    return _FULL_REF[key]
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("invariant,C,O", [("latitude_periodic", 32, 3), ("polar_periodic", 32, 3), ("rel_pos_periodic", 16, 1)])
+def test_backward_at_bench_latent_count(cuda, invariant, C, O, precision):
+    """The backward the bench runs for BASELINE configs 3 and 4, at their own shape: 128 latents, num_hidden 128, two heads,
+    512 sampled points (config_shallow_water.yaml:39-55,73: latitude_periodic, latent_dim 32, 3 fields; polar_periodic is the
+    SO(3) bi-invariant of the same shape; config 4 = rel_pos_periodic with 128 latents), against fp64 autograd of the oracle
+    under both backward kernel variants -- the z-fold kernel with its per-latent panels at Z = 128 included."""
+    cfg, prm, (x, p, a, s, w), (ro, rp, ra, rs) = _full_size_case(invariant, C, O, 128, 512, 77)
+    nef = build_nef(cfg, precision)
+    out, gp, ga, gs = hip_grads(cuda, nef, prm, x, p, a, s, w)
+    assert np.abs(out - ro).max() / np.abs(ro).max() < (2e-5 if precision == "f32" else 3e-2)
+    for k, g, r in (("p", gp, rp), ("a", ga, ra), ("sigma", gs, rs)):
+        assert rel(g, r) < TOL[precision], (invariant, precision, k, rel(g, r))
+
+
 def test_backward_no_window(cuda):
     cfg = make_cfg("rel_pos", use_window=False, freq=(0.5, 0.5))
     check(cuda, cfg, B=2, N=64, Z=8, precision="f32")

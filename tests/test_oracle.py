@@ -204,11 +204,24 @@ def test_oracle_reproduces_golden(name):
     kw, B, N, Z, seed, store_w = CASES[name]
     cfg = make_cfg(**kw)
     g = np.load(os.path.join(GOLD, name + ".npz"))
+    from tests.golden.make_golden import flatten, unflatten
     prm = R.init_params(int(g["param_seed"]), cfg, jitter=float(g["jitter"]))
-    out = R.nef_apply(prm, cfg, g["x"], g["p"], g["a"], g["sigma"])
-    assert np.abs(out - g["out"]).max() < 1e-12
+    stored = unflatten(g)
+    if stored is not None and name != "tiny_rel_pos_periodic":
+        # the fixture carries its weights: outputs and gradients belong to exactly those (fp32-representable) values,
+        # independent of init_params' random stream
+        out = R.nef_apply(stored, cfg, g["x"], g["p"], g["a"], g["sigma"])
+        assert np.abs(out - g["out"]).max() < 1e-12
+        tp = T.to_torch(stored, torch.float64)
+        tpp, ta, ts = (torch.tensor(g[k], requires_grad=True) for k in ("p", "a", "sigma"))
+        (T.nef_apply(tp, cfg, torch.tensor(g["x"]), tpp, ta, ts) * torch.tensor(g["w"])).sum().backward()
+        for key, ten in (("dp", tpp), ("da", ta), ("dsigma", ts)):
+            assert np.abs(ten.grad.numpy() - g[key]).max() < 1e-9 * max(1.0, np.abs(g[key]).max()), key
+    else:
+        out = R.nef_apply(prm, cfg, g["x"], g["p"], g["a"], g["sigma"])
+        assert np.abs(out - g["out"]).max() < 1e-12
     if store_w:   # the stored fp32 weights are the seeded weights
-        from tests.golden.make_golden import flatten
+        assert stored is not None
         for k, v in flatten(prm["params"]).items():
             assert np.allclose(g["W/" + k], v, rtol=1e-6, atol=1e-7)
 
