@@ -21,6 +21,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
                      step (K2 at the decode shape, K2 at the fit shape, K3 at the fit shape), `roofline_step` the aggregate.
   meta_step        : one OUTER step of the trainer (meta-gradient through the inner steps, the flat all-reduce of the outer
                      gradients -- inside the timed region --, clip + AdamW): the part of the path that has a collective.
+  timing           : `value` is the contract's wall-clock mean over exactly --steps steps; `timing.events` is the same step timed
+                     per iteration with events on the launch stream, median of --events-steps (100) steps.
+  accuracy         : field MSE of the HIP decode of this run's fitted latents against the fp64 oracle on 2 signals x 256 points.
   cpu_baseline     : the un-fused PyTorch-CPU restatement of the reference (oracle/, "port": JAX is not installable here)
                      timed on this box's host cores on a bounded sample, plus a 1-thread figure.
 """
@@ -252,6 +255,51 @@ def split_leg(c, m, coords, dcoords, img, device, iters=10):
     fit_pts = c["B"] * (c["S"] + 1) * min(c["N_s"], n)
     return {"qps_fit": round(fit_pts / t_fit, 1), "qps_decode": round((c["B"] * points_per_signal(c) - fit_pts) / t_dec, 1),
             "ms_fit": round(t_fit * 1e3, 4), "ms_decode": round(t_dec * 1e3, 4), "n_gpus": 1}
+
+
+# ---------------------------------------------------------------------------------------------------------- accuracy / timing
+def accuracy_leg(c, m, coords, lat, device, signals=2, queries=256):
+    """Field MSE of the HIP decode against the fp64 oracle on a small sub-sample of THIS run's fitted latents (BASELINE.json:
+    'field MSE vs JAX ref'; the oracle is the CPU restatement of the reference, parity unpinned -- DESIGN.md 2), outside the
+    timed region, rank 0.  The oracle is the checker here, as in the cpu_baseline leg; nothing of it is timed or shipped."""
+    import numpy as np
+    from oracle import enf_ref_np as R
+    cfg = dict(num_hidden=c["D"], num_heads=c["H"], latent_dim=c["C"], num_out=c["O"], invariant=c["inv"], num_in=2,
+               embedding_freq_multiplier=c["freq"], use_gaussian_window=True)
+    nb = min(signals, c["B"])
+    idx = torch.randperm(coords.shape[0], generator=torch.Generator().manual_seed(11))[:queries].to(device)
+    x = coords[idx][None].expand(nb, -1, -1).contiguous()
+    p, a, s = (v[:nb].contiguous() for v in (pose_of(lat), lat["a"], lat["gaussian_window"]))
+    with torch.no_grad():
+        got = m.nef.apply(m.params, x, p, a, s).double().cpu().numpy()
+
+    def to_np(t):
+        return {k: to_np(v) if isinstance(v, dict) else v.detach().double().cpu().numpy() for k, v in t.items()}
+    ref = R.nef_apply(to_np(m.params), cfg, *(v.double().cpu().numpy() for v in (x, p, a, s)))
+    err = got - ref
+    return {"mse_vs_oracle": float((err ** 2).mean()), "max_abs_err": float(np.abs(err).max()), "field_rms": float(np.sqrt((ref ** 2).mean())),
+            "n": int(err.size), "sample": f"{nb} fitted signals x {queries} grid points, {m.nef.precision} kernels vs fp64 oracle",
+            "budget": 1e-5}
+
+
+def events_leg(c, m, coords, dcoords, img, device, steps=100):
+    """The step timed per iteration with events on the launch stream (torch's current stream: the library joins its side
+    stream back into it before returning), `steps` iterations after the timed region: median and mean.  The contract's
+    `value` stays the wall-clock figure over exactly --steps steps between barriers; this is the BASELINE.md 2.2 protocol
+    (events, median of >= 100) beside it."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize(device)
+    ev[0].record()
+    for i in range(steps):
+        step(c, m, coords, dcoords, img)
+        ev[i + 1].record()
+    torch.cuda.synchronize(device)
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    med = ts[steps // 2] if steps % 2 else 0.5 * (ts[steps // 2 - 1] + ts[steps // 2])
+    pts = c["B"] * points_per_signal(c)
+    return {"steps": steps, "ms_median": round(med, 4), "ms_mean": round(sum(ts) / steps, 4), "ms_min": round(ts[0], 4),
+            "ms_p90": round(ts[int(0.9 * (steps - 1))], 4), "qps_median_per_gpu": round(pts / (med * 1e-3), 1),
+            "clock": "hipEvent pairs around each step on the launch stream, rank 0, after the timed region"}
 
 
 # ---------------------------------------------------------------------------------------------------------- roofline
@@ -557,6 +605,8 @@ def main():
     ap.add_argument("--no-ode", action="store_true", help="skip the latent-ODE evaluation leg (config 2, one GPU)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs")
     ap.add_argument("--kernel-iters", type=int, default=20, help="launches per timed per-kernel leg")
+    ap.add_argument("--events-steps", type=int, default=100, help="steps of the per-step event timing (median) reported beside `value`; 0 = skip")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the field-MSE-vs-oracle check of the fitted latents")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run ONLY the per-kernel legs and print them (for rocprofv3 --kernel-trace --stats: the profile then "
                          "holds exactly the launches the legs time, so its per-kernel averages are the legs' launch_ms)")
@@ -618,11 +668,17 @@ def main():
                    "num_hidden": c["D"], "num_heads": c["H"], "latent_dim": c["C"], "num_out": c["O"], "invariant": c["inv"],
                    "hparams": c["src"], "parallelism": f"dp{world} (signals sharded, no data-path collective in fit/decode)"},
         "final_fit_loss": round(float(loss), 6),
+        "timing": {"value_from": "wall clock over exactly --steps steps between barrier + synchronize, max over ranks (the contract)"},
     }
     if not args.no_meta and not c.get("rollout"):
         meta = meta_leg(c, m, coords, img, device, world)          # every rank: the outer step has the collective
         result["meta_step"] = meta
     if rank == 0:
+        if args.events_steps > 0:
+            result["timing"]["events"] = events_leg(c, m, coords, dcoords, img, device, args.events_steps)
+        if not args.no_accuracy:
+            _, lat_fit = fit(m, coords, img)
+            result["accuracy"] = accuracy_leg(c, m, dcoords, lat_fit, device)
         result["split"] = split_leg(c, m, coords, dcoords, img, device)
         result["roofline_step"] = step_roofline(c, ms_per_step, args.precision)
         if not args.no_roofline:

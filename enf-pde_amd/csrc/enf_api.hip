@@ -85,8 +85,8 @@ extern "C" size_t enf_workspace_bytes(const EnfDesc* d) {
 }
 
 // Side streams.  Work that can overlap the caller's stream (the z-fold backward's per-latent matrices) runs on ONE side
-// stream per device, created at the first call that needs it on that device; ENF_SIDE_STREAM=0 in the environment
-// disables it.  Fork / join is by events, so the caller's stream order is preserved.  What a forward leaves pending for
+// stream per device, created at the first call that needs it on that device (an -DENF_AB_SWITCHES build can disable it with
+// ENF_SIDE_STREAM=0).  Fork / join is by events, so the caller's stream order is preserved.  What a forward leaves pending for
 // its backward (ENF_STAGE_PREPARE_BWD) is recorded against the WORKSPACE it was prepared in, with an event of its own:
 // only a call on that workspace sees it.  One mutex per device keeps host threads from interleaving their record / wait
 // pairs on the shared fork event.
@@ -114,7 +114,11 @@ static SideStream* side_stream() {      // of the calling thread's current devic
   static std::mutex table_mu;
   static SideStream* table[ENF_MAX_DEVICES] = {};
   static bool tried[ENF_MAX_DEVICES] = {};
+#ifdef ENF_AB_SWITCHES     // A/B builds only (scripts/build_variant.sh NAME -DENF_AB_SWITCHES): the product library reads no environment
   static const bool enabled = [] { const char* e = getenv("ENF_SIDE_STREAM"); return !(e && e[0] == '0'); }();
+#else
+  constexpr bool enabled = true;
+#endif
   int dev = 0;
   if (!enabled || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ENF_MAX_DEVICES) return nullptr;
   std::lock_guard<std::mutex> lk(table_mu);
@@ -289,13 +293,19 @@ extern "C" int enf_lt_layout_ext(const EnfDesc* d, int* off_ext, int* off_phase_
   return ENF_OK;
 }
 
-// ENF_ZFOLD / ENF_ZFOLD_BWD in the environment (read once, immutable afterwards): the variant ENF_VARIANT_AUTO resolves
-// to, for A/B runs of a whole program.  Per call: EnfDesc.pair_fwd_variant / pair_bwd_variant.
+// What ENF_VARIANT_AUTO resolves to is a function of the shape alone (enf_layout.h); per call the caller chooses with
+// EnfDesc.pair_fwd_variant / pair_bwd_variant.  Only an -DENF_AB_SWITCHES build (A/B runs of a whole program) looks at
+// ENF_ZFOLD / ENF_ZFOLD_BWD in the environment (read once).
 int enf_zfold_env(int backward) {
+#ifdef ENF_AB_SWITCHES
   static const int mode[2] = {
       [] { const char* e = getenv("ENF_ZFOLD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }(),
       [] { const char* e = getenv("ENF_ZFOLD_BWD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }()};
   return mode[backward ? 1 : 0];
+#else
+  (void)backward;
+  return -1;
+#endif
 }
 
 extern "C" int enf_pair_variant(const EnfDesc* d, int backward) {

@@ -540,8 +540,13 @@ template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd
 #ifndef ENF_LN_APPLY_ASM
 #define ENF_LN_APPLY_ASM 2
 #endif
+#ifdef ENF_LN_FORM           // investigation builds: one explicit packed-operand form (scripts/k3_race/ln_forms.h)
+#include "../../scripts/k3_race/ln_forms.h"
+#endif
 template <int NT> DEV void ln_apply(f32x4 (&X)[NT], float mu, float rstd) {
-#if ENF_LN_APPLY_ASM == 2
+#ifdef ENF_LN_FORM
+  ln_apply_form<NT>(X, mu, rstd);
+#elif ENF_LN_APPLY_ASM == 2
   // as below, with the wait states where the hazards are instead of one s_nop per element: ONE in front (rstd comes out of
   // v_rsq_f32, and a transcendental's result needs a wait state before a VALU read the compiler cannot see), and the two of
   // VALU -> MFMA operand behind the LAST fma, tied to every tile by data dependence (an asm without operands orders only

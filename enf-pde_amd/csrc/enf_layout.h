@@ -194,9 +194,9 @@ ENF_HD inline int enf_lt_off_c(int H, int D) { return 2 * H * D + 8; }
 // into ONE per-latent D x D matrix  W_zh = (Wgamma_h diag(v0_zh) + Wbeta_h) AM  (no nonlinearity
 // sits between them), built by enf_wz_kernel into `wz` before the pair kernel runs.  It needs
 // enough 128-query workgroups to fill the chip; below that the latent-split variant runs.
-// EnfDesc.pair_fwd_variant forces the choice per call; for ENF_VARIANT_AUTO, ENF_ZFOLD=0 / 1 in the environment (read
-// once) replaces the heuristic (A/B runs of a whole program).
-int enf_zfold_env(int backward);   // enf_api.hip: -1 unset, 0 / 1
+// EnfDesc.pair_fwd_variant forces the choice per call; ENF_VARIANT_AUTO is the heuristic below, a function of the shape
+// alone (only an -DENF_AB_SWITCHES build of the library lets ENF_ZFOLD=0 / 1 in the environment replace it).
+int enf_zfold_env(int backward);   // enf_api.hip: -1 (always, in the product library), 0 / 1
 inline bool enf_use_zfold(const EnfDims& m) {
   // one signal's folded matrices sit behind a buffer resource with 32-bit offsets: beyond 2 GB per signal (Z >= 32768
   // at D = 128, H = 2) only the latent-split variant can run
@@ -211,7 +211,7 @@ ENF_HD inline size_t enf_wzu_bytes(int H, int D) { return (size_t)(D / 32) * 4 *
 
 // Backward counterpart (enf_pair_bwd_kernel<.., ZF = true>): one workgroup per latent, its 8 waves take 8 query
 // tiles at a time, so the per-latent matrices W_zh (both orientations) stream through the LDS ring shared by the
-// workgroup.  Needs enough latents to fill the chip.  EnfDesc.pair_bwd_variant / ENF_ZFOLD_BWD=0/1 as for the forward.
+// workgroup.  Needs enough latents to fill the chip.  EnfDesc.pair_bwd_variant as for the forward.
 inline bool enf_use_zfold_bwd(const EnfDims& m) {
   if (m.var_bwd != ENF_VARIANT_AUTO) return m.var_bwd == ENF_VARIANT_ZFOLD;
   const int mode = enf_zfold_env(1);

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void enf_ode_block_bwd_kernel(BkArgs A) {
 }
 
 // out[e] = sum over w of part[w][e]: 32 elements x 8 groups per block, fixed order
-__global__ __launch_bounds__(256) void enf_ode_block_sum_kernel(const float* part, int nwg, int n, float* out) {
+__global__ __launch_bounds__(256) void enf_ode_block_sum_kernel(const float* part, int nwg, int n, float* out, int accumulate) {
   __shared__ float red[8][32];
   const int e = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
   float s = 0.f;
@@ -272,17 +272,22 @@ __global__ __launch_bounds__(256) void enf_ode_block_sum_kernel(const float* par
   if (grp == 0 && e < n) {
     float t = 0.f;
     for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x & 31];
-    out[e] = t;
+    out[e] = accumulate ? out[e] + t : t;
   }
 }
 
 // --------------------------------------------------------------------------------------------------------------- host
+constexpr int BK_CHUNK_WGS = 256;       // rows per backward chunk = 16 x this
+
 extern "C" int enf_ode_block_supported(int H, int M) {
   return (H == 32 || H == 64 || H == 128) && M == 2 * H ? 1 : 0;
 }
 extern "C" size_t enf_ode_block_scratch_bytes(int64_t R, int H, int M) {
   if (!enf_ode_block_supported(H, M) || R <= 0) return 0;
-  return 4 * (size_t)((R + 15) / 16) * (2 * (size_t)H * M + M + 3 * H);
+  // one partial (2 H M + M + 3 H floats, 265 KB at H = 128) per 16-row workgroup of a CHUNK of at most BK_CHUNK_WGS workgroups:
+  // the backward walks larger inputs chunk by chunk, so the scratch stays bounded (68 MB at H = 128) whatever R is
+  const int64_t nwg = (R + 15) / 16;
+  return 4 * (size_t)(nwg < BK_CHUNK_WGS ? nwg : BK_CHUNK_WGS) * (2 * (size_t)H * M + M + 3 * H);
 }
 
 extern "C" int enf_ode_block_forward(int64_t R, int H, int M, const float* x, const float* gamma, const float* beta,
@@ -316,14 +321,21 @@ extern "C" int enf_ode_block_backward(int64_t R, int H, int M, const float* x, c
   if (!enf_ode_block_supported(H, M)) return ENF_EUNSUPPORTED;
   if (!x || !gamma || !beta || !W1 || !W2 || !pre || !g || !dx || !dparams || !scratch) return ENF_EINVAL;
   if (scratch_bytes < enf_ode_block_scratch_bytes(R, H, M) || ((uintptr_t)scratch & 15)) return ENF_EINVAL;
-  BkArgs A{x, gamma, beta, W1, nullptr, W2, nullptr, nullptr, const_cast<float*>(pre), g, dx, (float*)scratch, (int)R, eps};
-  const int nwg = (int)((R + 15) / 16), n = 2 * H * M + M + 3 * H;
+  const int n = 2 * H * M + M + 3 * H;
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (H == 32) rc = bk_launch_bwd<2, 4>(A, dim3(nwg), st);
-  else if (H == 64) rc = bk_launch_bwd<4, 8>(A, dim3(nwg), st);
-  else rc = bk_launch_bwd<8, 16>(A, dim3(nwg), st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(enf_ode_block_sum_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)scratch, nwg, n, dparams);
+  const int64_t chunk_rows = 16ll * BK_CHUNK_WGS;
+  for (int64_t r0 = 0; r0 < R; r0 += chunk_rows) {
+    const int rows = (int)(R - r0 < chunk_rows ? R - r0 : chunk_rows);
+    BkArgs A{x + r0 * H, gamma, beta, W1, nullptr, W2, nullptr, nullptr, const_cast<float*>(pre) + r0 * M, g + r0 * H, dx + r0 * H,
+             (float*)scratch, rows, eps};
+    const int nwg = (rows + 15) / 16;
+    int rc;
+    if (H == 32) rc = bk_launch_bwd<2, 4>(A, dim3(nwg), st);
+    else if (H == 64) rc = bk_launch_bwd<4, 8>(A, dim3(nwg), st);
+    else rc = bk_launch_bwd<8, 16>(A, dim3(nwg), st);
+    if (rc) return rc;
+    // (stream order: the next chunk's partials overwrite the scratch only after this sum has read it)
+    hipLaunchKernelGGL(enf_ode_block_sum_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)scratch, nwg, n, dparams, r0 > 0 ? 1 : 0);
+  }
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }

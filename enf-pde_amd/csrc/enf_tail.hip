@@ -350,9 +350,13 @@ static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
   using T = TailCfg<D, H, BF16>;
   dim3 grid((A.NQ + 16 * NWAVES - 1) / (16 * NWAVES));
   // few workgroups (at most one per CU): the deeper weight pipeline (LA2) instead of a second workgroup per CU
+#ifdef ENF_AB_SWITCHES       // A/B builds only: ENF_TAIL_LA2=0/1 forces the choice
   static int la2_mode = -1;
   if (la2_mode < 0) { const char* e = getenv("ENF_TAIL_LA2"); la2_mode = e ? (e[0] == '0' ? 0 : 1) : 2; }
   const bool la2 = la2_mode == 2 ? grid.x <= 256 : la2_mode == 1;
+#else
+  const bool la2 = grid.x <= 256;
+#endif
   // opt: forward -> stash the pre-activations (SAVE); backward -> they are stashed, skip the recompute
   static EnfAttrBits attr_done[2][2][2];     // [bwd][la2][opt] (this function is one instantiation per D, H, BF16), one bit per device
   auto go = [&](void (*kern_ptr)(TailArgs)) -> int {

@@ -204,8 +204,12 @@ static int launch_wz(const WzArgs& A, hipStream_t st) {
   // the backward's call (both orientations) runs on the side stream beside the tail kernels and is off the critical
   // path with half the chip (same-box A/B of the fit: 3.036 ms with 128 workgroups, 3.052 with 256); the decode's call
   // is ON the critical path and takes the whole chip
+#ifdef ENF_AB_SWITCHES       // A/B builds only: ENF_WZ_GRID=n overrides the workgroup count
   static int envgrid = -1;
   if (envgrid < 0) { const char* e = getenv("ENF_WZ_GRID"); envgrid = e ? atoi(e) : 0; if (envgrid == 1) envgrid = 2; }
+#else
+  constexpr int envgrid = 0;
+#endif
   const int maxgrid = envgrid > 0 ? envgrid : (A.wzt ? ENF_WZ_MAXGRID / 2 : ENF_WZ_MAXGRID);
   const int max_waves = maxgrid * WZ_WAVES;
   int lanes = A.BZ;

@@ -310,8 +310,22 @@ class EquivariantCrossAttentionNeF:
         P = params["params"] if "params" in params else params
         return [_get(P, path) for path in tensor_paths(self.num_layers)]
 
+    def invalidate_caches(self):
+        """Forget the packed-weight blob, the packed pair panels of the training path and the latent tables held in workspaces.
+
+        CONTRACT of the caches: reuse is decided from ``(tensor.data_ptr(), tensor._version)`` of the weight / latent tensors,
+        so an update is seen when it goes through torch (in-place ops bump ``_version``; the optimisers and
+        ``meta_sgd_update`` of this package return fresh tensors).  Writes torch cannot see -- through ``.data``, through a
+        detached alias made before the call, by a raw-pointer kernel, ``hipMemcpy`` or a collective on an alias -- leave
+        ``_version`` unchanged: call this method after such a write (``load_params`` does, for the tree it returns is new)."""
+        self._pack_cache.clear()
+        self._lt_held.clear()
+        self._pair_key = None
+        self._pair_blob = None
+
     def load_params(self, tree, device="cuda"):
         """Build a parameter tree from nested numpy / torch arrays (e.g. an exported Flax tree)."""
+        self.invalidate_caches()
         P = tree["params"] if "params" in tree else tree
         out = {}
         for path in tensor_paths(self.num_layers):

@@ -95,8 +95,8 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
         st = ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
         if out.shape != ys_all[S].shape:
             raise AssertionError(f"targets have shape {tuple(ys_all[S].shape)}, expected {tuple(out.shape)}")
-        _lib.check(_lib.load().enf_mse_value_grad(out.data_ptr(), ys_all[S].data_ptr(), out.numel(), 1.0, None,
-                                                  losses[S:].data_ptr(), st))
+        _lib.launch(out.device, _lib.load().enf_mse_value_grad, out.data_ptr(), ys_all[S].data_ptr(), out.numel(), 1.0, None,
+                    losses[S:].data_ptr(), st)
     return losses[S], lat
 
 

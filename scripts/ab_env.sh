@@ -1,5 +1,7 @@
 #!/bin/bash
 # Same-box A/B of bench.py over values of one environment variable: scripts/ab_env.sh VAR v1 v2 ...   (3 rounds)
+# The library's own switches (ENF_ZFOLD, ENF_ZFOLD_BWD, ENF_SIDE_STREAM, ENF_TAIL_LA2, ENF_WZ_GRID) exist only in a build with
+# -DENF_AB_SWITCHES: scripts/build_variant.sh ab -DENF_AB_SWITCHES, then ENF_HIP_LIB=variants/libenf_ab.so scripts/ab_env.sh ...
 VAR=$1; shift
 for r in 1 2 3; do
   for v in "$@"; do

@@ -8,7 +8,7 @@ for rnd in range(int(os.environ.get("AB_ROUNDS", 2))):
         env = dict(os.environ)
         if lib != "-":
             env["ENF_HIP_LIB"] = os.path.abspath(lib)
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-meta", "--no-ode", "--kernel-iters", "60", "--steps", "40"], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-meta", "--no-ode", "--kernel-iters", "60", "--steps", "40", "--events-steps", "0", "--no-accuracy"], env=env, capture_output=True, text=True)
         try:
             d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             k = d["roofline_kernels"]

@@ -61,3 +61,52 @@ def test_single_process_is_a_noop():
     t = [torch.ones(3)]
     assert allreduce_mean_(t)[0].tolist() == [1.0, 1.0, 1.0]
     assert shard_range(10, 0, 1) == (0, 10)
+
+
+def _worker8(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(1)
+    from enf_pde_amd.fitting import init_distributed, shard_range, allreduce_mean_
+    r, w, _ = init_distributed(backend="gloo")
+    lo, hi = shard_range(total, r, w)
+    # per-signal "outer gradients" of three tensors of different shapes; each rank holds the MEAN over its shard, as the
+    # trainer's outer step does (fitting/trainers/pde_trainer.py: nef_train_step), and one flat weighted all-reduce must give
+    # the mean over all signals of the job -- also when the shards differ by one signal (62 = 6 x 8 + 2 x 7)
+    g = torch.Generator().manual_seed(7)
+    per_signal = [torch.randn(total, 5, generator=g), torch.randn(total, 2, 3, generator=g), torch.randn(total, 1, generator=g)]
+    mine = [t[lo:hi].mean(0) for t in per_signal]
+    allreduce_mean_(mine, weight=hi - lo)
+    err = max(float((m - t.mean(0)).abs().max()) for m, t in zip(mine, per_signal))
+    q.put((r, lo, hi, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run8(total):
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_eight_rank_gloo_weighted_allreduce_equal_and_unequal_shards():
+    """BASELINE config 4's exchange step at its rank count (meta-batch 64 over 8 ranks), on CPU / gloo: 64 signals
+    give 8 x 8 shards, 62 give uneven ones; the single weighted all-reduce reproduces the global-batch mean in both."""
+    res = _run8(64)
+    assert [(lo, hi) for _, lo, hi, _ in res] == [(8 * r, 8 * r + 8) for r in range(8)]
+    assert max(e for *_, e in res) < 1e-5
+    res = _run8(62)
+    sizes = [hi - lo for _, lo, hi, _ in res]
+    assert sizes == [8] * 6 + [7] * 2 and res[0][1] == 0 and res[-1][2] == 62
+    assert all(res[i][2] == res[i + 1][1] for i in range(7))          # contiguous, disjoint
+    assert max(e for *_, e in res) < 1e-5

@@ -74,25 +74,31 @@ def test_two_ranks_share_one_outer_step(cuda):
     assert ((w - wa).abs() < 2e-4).float().mean() > 0.97 and ((o - oa).abs() < 2e-4).float().mean() > 0.97
 
 
-def test_bench_spawns_its_own_ranks(cuda):
-    """`bench.py --gpus 2` with no torchrun environment launches two ranks itself (here both on the one GPU, over gloo:
-    ENF_BENCH_SHARE_GPU=1, a rehearsal switch) and the line it prints says two ranks ran, with the outer step's all-reduce
-    inside the timed meta_step leg."""
+@pytest.mark.parametrize("gpus,config", [(2, 2), (4, 4)])
+def test_bench_spawns_its_own_ranks(cuda, gpus, config):
+    """`bench.py --gpus N` with no torchrun environment launches N ranks itself (here all on the one GPU, over gloo:
+    ENF_BENCH_SHARE_GPU=1, a rehearsal switch) and the line it prints says N ranks ran, with the outer step's all-reduce
+    inside the timed meta_step leg.  (4, 4): BASELINE config 4's data-parallel workload (128 latents, 128 x 128 grid, 8 signals
+    per rank) at the largest rank count one GPU box admits (its process guard allows 6 GPU processes; the 8-rank exchange
+    itself is covered on CPU: tests/test_dist_gloo.py)."""
     import json
     import subprocess
     import sys
+    from bench import CONFIGS
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["ENF_BENCH_SHARE_GPU"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    steps = 2 if gpus == 2 else 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--config", str(config), "--steps", str(steps),
+                        "--warmup", "1", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2")
-    assert d["meta_step"]["n_gpus"] == 2 and "gloo" in d["meta_step"]["collective"] and d["meta_step"]["ms_per_step"] > 0
-    one = 16 * (4 * 512 + 4096)
-    assert abs(d["value"] - 2 * one * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]      # the whole job's points / time
+    assert d["n_gpus"] == gpus and d["config"]["parallelism"].startswith(f"dp{gpus}") and d["scaling"] == "weak"
+    assert d["meta_step"]["n_gpus"] == gpus and "gloo" in d["meta_step"]["collective"] and d["meta_step"]["ms_per_step"] > 0
+    c = CONFIGS[config]
+    one = c["B"] * ((c["S"] + 1) * c["N_s"] + c["grid"][0] * c["grid"][1])
+    assert abs(d["value"] - gpus * one * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-3 * d["value"]      # the whole job's points / time
 
 
 @pytest.mark.parametrize("flags", [["--config", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],

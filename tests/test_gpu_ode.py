@@ -109,11 +109,12 @@ def test_kernel_basis_wide_hidden_and_fallbacks(cuda):
         assert torch.isfinite(xg.grad).all()
 
 
-@pytest.mark.parametrize("B,Z,H", [(16, 64, 128), (3, 7, 64), (2, 9, 32), (1, 33, 128)])
+@pytest.mark.parametrize("B,Z,H", [(16, 64, 128), (3, 7, 64), (2, 9, 32), (1, 33, 128), (5, 1000, 32)])
 def test_latent_block_fused_matches_definition(cuda, B, Z, H):
     """enf_ode_block_forward / _backward (csrc/enf_ode_block.hip) against the definition in fp64 -- LayerNorm(1e-6) -> Dense ->
     gelu -> Dense (ConvBlock, ponita_ode_g.py:44-48): values and every gradient; row counts that are not multiples of 16; the
-    library-GEMM path of the same autograd node (other widths) agrees too; two runs bitwise equal."""
+    library-GEMM path of the same autograd node (other widths) agrees too; two runs bitwise equal.  (5, 1000, 32): 5000 rows,
+    more than one backward chunk of 4096 rows -- the weight gradients accumulate over chunks in a scratch of bounded size."""
     from enf_pde_amd.fitting.ode_models import ponita_ode_g as M_
     g = torch.Generator().manual_seed(B * 100 + Z + H)
     mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)

@@ -412,29 +412,44 @@ def test_train_state_checkpoint_keeps_dtypes_and_rng(tmp_path):
     assert tr["count"].dtype == torch.int64 and tr["w"].dtype == torch.float32
 
 
-def test_pair_kernels_carry_no_packed_add_with_a_negated_high_register_broadcast(tmp_path):
-    """The instruction form behind the "K3 run-to-run deviations" (scripts/k3_race/README.md): `v_pk_add_f32` whose second operand is
-    the HIGH register of a pair broadcast by `op_sel:[0,1]` and negated -- what hipcc's SLP vectoriser makes of a plain
-    `x = (x - mu) * rstd` loop.  The LayerNorm applies go through ln_apply (scalar asm fmas) instead; a new loop of that shape, or
-    a compiler that packs differently, would bring the form back without any parity test noticing (it misbehaves about once
-    per 10^5 executions), so the emitted code of the kernels that had it is checked here."""
+def test_emitted_kernels_carry_no_known_unsafe_instruction_form(tmp_path):
+    """Emitted-code guards over EVERY kernel source of the library (the Makefile's SRCS), one `hipcc -S` each:
+    (1) the instruction form behind the "K3 run-to-run deviations" (scripts/k3_race/README.md): `v_pk_add_f32` whose second operand
+        is the HIGH register of a pair broadcast by `op_sel:[0,1]` and negated -- what hipcc's SLP vectoriser makes of a plain
+        `x = (x - mu) * rstd` loop.  The LayerNorm applies go through ln_apply (scalar asm fmas) instead; a new loop of that shape, or
+        a compiler that packs differently, would bring the form back without any parity test noticing (it misbehaved about once
+        per 10^5 executions).  The other packed operand forms the kernels contain were run in the same context and did not deviate
+        where the controls did (README, "Packed-operand forms"), so only this form is rejected;
+    (2) no vector instruction inside an inline-asm block (invisible to hipcc's hazard recognizer) feeds a v_mfma operand with fewer
+        than the two wait states gfx950 needs, and no asm transcendental feeds a VALU without one (scripts/check_mfma_hazards.py,
+        rule 2; scripts/ubench/valu_mfma_hazard.hip, trans_hazard.hip) -- fp32 instantiations included, whose MFMA operands ARE the
+        registers ln_apply writes."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "enf-pde_amd", "csrc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "enf-pde_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^SRCS\s*=\s*(.+)$", mk, re.M).group(1).split()
+    assert len(srcs) >= 11 and "enf_pair_bwd" in srcs and "enf_tail" in srcs
     procs = {}
-    for f in ("enf_pair_bwd", "enf_tail"):
+    for f in srcs:
         out = str(tmp_path / (f + ".s"))
         procs[f] = (out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unknown-pragmas",
                                            "--cuda-device-only", "-S", os.path.join(csrc, f + ".hip"), "-o", out],
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     form = re.compile(r"v_pk_add_f32\b.*op_sel:\[0,1\].*neg_lo:\[0,1\]")
     for f, (out, pr) in procs.items():
-        _, err = pr.communicate(timeout=600)
+        _, err = pr.communicate(timeout=900)
         assert pr.returncode == 0, err.decode()[-2000:]
         text = open(out).read()
-        assert "v_mfma" in text                                             # (really the device code)
+        has_kernels = "__global__" in open(os.path.join(csrc, f + ".hip")).read()
+        assert ("s_endpgm" in text) == has_kernels                          # (really the device code; enf_api.hip is host-only)
         hits = [ln.strip() for ln in text.splitlines() if form.search(ln)]
         assert not hits, f"{f}: {len(hits)} x the failing form, e.g. {hits[0]}"
+        chk = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_mfma_hazards.py"), out], capture_output=True, text=True)
+        assert chk.returncode == 0, chk.stderr[-1000:]
+        asm_hits = [ln for ln in chk.stdout.splitlines() if " asm " in ln]
+        assert not asm_hits, f"{f}: {asm_hits[:3]}"
