@@ -136,7 +136,9 @@ static SideStream* side_stream() {      // of the calling thread's current devic
 
 // join the side-stream work an earlier ENF_STAGE_PREPARE_BWD left pending on THIS workspace (no matching backward
 // came) before `st` touches the regions it writes
-static int side_join_pending(hipStream_t st, const void* workspace) {
+int enf_side_join_pending(hipStream_t st, const void* workspace);
+static int side_join_pending(hipStream_t st, const void* workspace) { return enf_side_join_pending(st, workspace); }
+int enf_side_join_pending(hipStream_t st, const void* workspace) {
   SideStream* side = side_stream();
   if (!side) return 0;
   std::lock_guard<std::mutex> lk(side->mu);

@@ -505,6 +505,8 @@ struct PrologueBwdArgs {
   float* dp; float* da; float* dsigma;
   int BZ, H, D, C, dp_dim, inv;
   int Dt;
+  float* pg;     // weight-gradient backward (or NULL): per latent row [d k (HD) | d an (D) | d s (D) | an (D) | d an * xn (D) | d c_h k_h (HD)],
+                 // the operands of the prologue's X^T delta products and column sums (enf_train.hip); an = the LayerNorm's affine output
 };
 
 __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A) {
@@ -549,7 +551,14 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
       }
     }
 #pragma unroll
-    for (int zz = 0; zz < ZT; ++zz) s_dk[j * ZT + zz] = acc[zz];
+    for (int zz = 0; zz < ZT; ++zz) {
+      s_dk[j * ZT + zz] = acc[zz];
+      if (A.pg && row0 + zz < A.BZ) {
+        float* pr = A.pg + (size_t)(row0 + zz) * (2 * HD + 4 * D);
+        pr[j] = acc[zz];
+        pr[HD + 4 * D + j] = s_dc[h * ZT + zz] * A.kv[(size_t)(row0 + zz) * 2 * HD + j];
+      }
+    }
   }
   __syncthreads();
   // d(an_affine)[d] = sum_j Wk[d][j] dk[j] + Wv[d][j] dv0[j]  (wkT/wvT: [j][d]); then through scale: dxn = dy * g.
@@ -581,6 +590,13 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
         float v = 0.f;
         for (int q = 0; q < nsplit; ++q) v += s_part[(q * D + tid) * ZT + zz];
         s_dan[tid * ZT + zz] = v * g;
+        if (A.pg && row0 + zz < A.BZ) {
+          float* pr = A.pg + (size_t)(row0 + zz) * (2 * HD + 4 * D) + HD;
+          const float xn = A.an[(size_t)(row0 + zz) * (2 * D + 2) + D + tid];
+          pr[tid] = v;
+          pr[2 * D + tid] = xn * g + W(A.L.lna_b)[tid];
+          pr[3 * D + tid] = v * xn;
+        }
       }
     }
   }
@@ -594,7 +610,11 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
     for (int d = lane; d < D; d += 64) { const float g = s_dan[d * ZT + zz]; v1 += g; v2 += g * anr[D + d]; }
     const float m1 = wave_sum(v1) / A.Dt, m2 = wave_sum(v2) / A.Dt;
     const float rstd = anr[2 * D + 1];
-    for (int d = lane; d < D; d += 64) s_dan[d * ZT + zz] = rstd * (s_dan[d * ZT + zz] - m1 - anr[D + d] * m2);
+    for (int d = lane; d < D; d += 64) {
+      const float ds = rstd * (s_dan[d * ZT + zz] - m1 - anr[D + d] * m2);
+      s_dan[d * ZT + zz] = ds;
+      if (A.pg && r < A.BZ) A.pg[(size_t)r * (2 * HD + 4 * D) + HD + D + d] = ds;
+    }
   }
   __syncthreads();
   // da[c] = sum_d Ws[c][d] ds[d]
@@ -636,10 +656,19 @@ __global__ __launch_bounds__(256) void enf_prologue_bwd_kernel(PrologueBwdArgs A
   }
 }
 
+extern "C" int enf_launch_prologue_bwd_wg(const EnfDims& m, const EnfLayout& L, const char* blob, const float* p,
+                                          const float* sigma, const float* an, const float* kv, const float* dlt, float* dp,
+                                          float* da, float* dsigma, float* pg, hipStream_t st);
 extern "C" int enf_launch_prologue_bwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* p,
                                        const float* sigma, const float* an, const float* kv, const float* dlt, float* dp,
                                        float* da, float* dsigma, hipStream_t st) {
+  return enf_launch_prologue_bwd_wg(m, L, blob, p, sigma, an, kv, dlt, dp, da, dsigma, nullptr, st);
+}
+extern "C" int enf_launch_prologue_bwd_wg(const EnfDims& m, const EnfLayout& L, const char* blob, const float* p,
+                                          const float* sigma, const float* an, const float* kv, const float* dlt, float* dp,
+                                          float* da, float* dsigma, float* pg, hipStream_t st) {
   PrologueBwdArgs A;
+  A.pg = pg;
   A.p = p; A.sigma = sigma; A.blob = blob; A.L = L; A.an = an; A.kv = kv; A.dlt = dlt;
   A.dp = dp; A.da = da; A.dsigma = dsigma;
   A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp_dim = m.dp; A.inv = m.inv; A.Dt = m.Dt;

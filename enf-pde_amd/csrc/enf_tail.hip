@@ -20,6 +20,8 @@ struct TailArgs {
   float* out;            // forward: (B*N, O)
   const float* dout;     // backward
   float* dybar; float* delta; float* act;   // backward outputs + scratch (B*N x (2HD + 2D + 2))
+  float* tdel;           // weight-gradient backward (WG): per query d a_B | d a_F1 | d a_O0 | d a_O2 (2HD + 2D floats); the layer INPUTS
+                         // n^ | gelu(a_F1) | gelu(a_O0) | gelu(a_O2) replace the pre-activations in `act` (enf_train.hip forms X^T delta)
   int NQ, O;             // NQ = B*N queries
   float inv_hd;          // 1 / (H * true num_hidden)
 };
@@ -122,7 +124,7 @@ DEV void tail_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, cha
 // two, or nothing); the 2-slot pipeline only uses the first stage of NX1.
 template <int D, int H, bool BF16, bool SAVE, bool LA2, typename NX1, typename NX2>
 DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLayout& L, const float* cst, Pipe& P,
-                      char* ring, unsigned next, unsigned next2, int lane, int quad, float inv_hd) {
+                      char* ring, unsigned next, unsigned next2, int lane, int quad, float inv_hd, bool save_ok = true) {
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
   using PTB = Pan<KBH, NTH, BF16>; using PO0 = Pan<KBH, NT, BF16>; using PO2 = Pan<KB, NT, BF16>; using PO4 = Pan<KB, 2, BF16>;
@@ -135,20 +137,20 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
 #pragma unroll
   for (int t = 0; t < NTH; ++t) a[t] = rowvec(c_bB, t, quad);
   tail_gemm<LA2, KBH, NTH, BF16, PTB, PO0, T::ST_TB>(a, FH, P, ring, (unsigned)L.atb, (unsigned)L.atf1, (unsigned)L.ato0, lane);
-  if (SAVE) store_rows<NTH>(a, act, quad);
+  if (SAVE && save_ok) store_rows<NTH>(a, act, quad);
 #pragma unroll
   for (int t = 0; t < NTH; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[t][i] = gelu_f(a[t][i]);
   float mu, rstd;
   ln_stats<NTH>(a, mu, rstd, inv_hd);
-  if (SAVE && quad == 0) { act[T::ACT - 2] = mu; act[T::ACT - 1] = rstd; }
+  if (SAVE && save_ok && quad == 0) { act[T::ACT - 2] = mu; act[T::ACT - 1] = rstd; }
   ln_apply<NTH>(a, mu, rstd);          // (scalar fmas on purpose: enf_device.h)
   make_frags<BF16, KBH>(FH, a);
 #pragma unroll
   for (int t = 0; t < NTH; ++t) a[t] = rowvec(c_bF1, t, quad);
   tail_gemm<LA2, KBH, NTH, BF16, PO0, PO2, T::ST_O0>(a, FH, P, ring, (unsigned)L.atf1, (unsigned)L.ato0, (unsigned)L.ato2, lane);
-  if (SAVE) store_rows<NTH>(a, act + HD, quad);
+  if (SAVE && save_ok) store_rows<NTH>(a, act + HD, quad);
 #pragma unroll
   for (int t = 0; t < NTH; ++t)
 #pragma unroll
@@ -158,7 +160,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
 #pragma unroll
   for (int t = 0; t < NT; ++t) c[t] = rowvec(c_bO0, t, quad);
   tail_gemm<LA2, KBH, NT, BF16, PO2, PO4, T::ST_O2>(c, FH, P, ring, (unsigned)L.ato0, (unsigned)L.ato2, (unsigned)L.ato4, lane);
-  if (SAVE) store_rows<NT>(c, act + 2 * HD, quad);
+  if (SAVE && save_ok) store_rows<NT>(c, act + 2 * HD, quad);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -168,7 +170,7 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
 #pragma unroll
   for (int t = 0; t < NT; ++t) c[t] = rowvec(c_bO2, t, quad);
   tail_gemm<LA2, KB, NT, BF16, PO4, NX1, T::ST_O4>(c, FD, P, ring, (unsigned)L.ato2, (unsigned)L.ato4, next, lane);
-  if (SAVE) store_rows<NT>(c, act + 2 * HD + D, quad);
+  if (SAVE && save_ok) store_rows<NT>(c, act + 2 * HD + D, quad);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   }
 }
 
-template <int D, int H, bool BF16, bool LA2, bool RECOMP>
+template <int D, int H, bool BF16, bool LA2, bool RECOMP, bool WG = false>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   const int qi = min(q0 + col, A.NQ - 1);
   // clamped (duplicate) queries write the same scratch values: benign
   float* act = A.act + (size_t)qi * T::ACT;
+  float* tdel = WG ? A.tdel + (size_t)qi * (2 * HD + 2 * D) : nullptr;
   const float* yrow = A.ybar + (size_t)qi * HD;
   tail_consts<D, H, BF16>(cst, A.blob, A.L, tid);
   Pipe P;
@@ -245,8 +248,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
       la2_first<PGH, PGH>(P, ring, (unsigned)A.L.atb, (unsigned)A.L.atf1, wave, lane);
     } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
     f32x4 o4[2];
+    // WG: the rows of `act` are rewritten in place below (layer inputs over pre-activations), so a clamped duplicate lane -- it shares
+    // its row with the query's own lane in another wave -- must not store: its late pre-activation would land on the finished row
     tail_forward<D, H, BF16, true, LA2, PG4, PG2>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, lane, quad,
-                                                  A.inv_hd);
+                                                  A.inv_hd, !WG || qvalid);
   } else {      // the forward of this step stashed the pre-activations (enf_tail_fwd_kernel<.., SAVE>): start at the backward chain
     if constexpr (LA2) {
       __syncthreads();
@@ -276,6 +281,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) c[t][i] *= gelu_grad_f(pre[t][i]);                                            // d a_O2
+    if constexpr (WG) {
+      if (qvalid) store_rows<NT>(c, tdel + 2 * HD + D, quad);      // (a clamped duplicate lane holds zeros: only the query's own lane writes)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[t][i] = gelu_f(pre[t][i]);
+      if (qvalid) store_rows<NT>(pre, act + 2 * HD + D, quad);                                                  // input of out_proj.layers_4
+    }
   }
   Frags<BF16, KB> FD;
   make_frags<BF16, KB>(FD, c);
@@ -288,6 +301,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) c[t][i] *= gelu_grad_f(pre[t][i]);                                            // d a_O0
+    if constexpr (WG) {
+      if (qvalid) store_rows<NT>(c, tdel + 2 * HD, quad);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[t][i] = gelu_f(pre[t][i]);
+      if (qvalid) store_rows<NT>(pre, act + 2 * HD, quad);                                                      // input of out_proj.layers_2
+    }
   }
   make_frags<BF16, KB>(FD, c);
   f32x4 a[NTH];
@@ -300,6 +321,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
     for (int t = 0; t < NTH; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[t][i] *= gelu_grad_f(pre[t][i]);                                            // d a_F1
+    if constexpr (WG) {
+      if (qvalid) store_rows<NTH>(a, tdel + HD, quad);
+#pragma unroll
+      for (int t = 0; t < NTH; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[t][i] = gelu_f(pre[t][i]);
+      if (qvalid) store_rows<NTH>(pre, act + HD, quad);                                                         // input of out_proj.layers_0
+    }
   }
   Frags<BF16, KBH> FH;
   make_frags<BF16, KBH>(FH, a);
@@ -325,7 +354,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
       for (int i = 0; i < 4; ++i) {
         const float nh = (gelu_f(pre[t][i]) - mu) * rstd;
         a[t][i] = rstd * (a[t][i] - m1 - nh * m2) * gelu_grad_f(pre[t][i]);                                     // d a_B
+        if constexpr (WG) pre[t][i] = nh;
       }
+    if constexpr (WG) {
+      if (qvalid) store_rows<NTH>(a, tdel, quad);
+      if (qvalid) store_rows<NTH>(pre, act, quad);                                                              // n^: input of the (folded) FFN Dense_1
+    }
   }
   make_frags<BF16, KBH>(FH, a);
   zero_tiles<NTH>(a);
@@ -347,6 +381,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
 
 template <int D, int H, bool BF16>
 static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
+  const bool wg = bwd && A.tdel != nullptr;
   using T = TailCfg<D, H, BF16>;
   dim3 grid((A.NQ + 16 * NWAVES - 1) / (16 * NWAVES));
   // few workgroups (at most one per CU): the deeper weight pipeline (LA2) instead of a second workgroup per CU
@@ -358,13 +393,17 @@ static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
   const bool la2 = grid.x <= 256;
 #endif
   // opt: forward -> stash the pre-activations (SAVE); backward -> they are stashed, skip the recompute
-  static EnfAttrBits attr_done[2][2][2];     // [bwd][la2][opt] (this function is one instantiation per D, H, BF16), one bit per device
+  static EnfAttrBits attr_done[3][2][2];     // [fwd / bwd / bwd + WG][la2][opt] (this function is one instantiation per D, H, BF16), one bit per device
   auto go = [&](void (*kern_ptr)(TailArgs)) -> int {
     const int smem = la2 ? T::SMEM3 : T::SMEM;
-    if (!enf_lds_attr(reinterpret_cast<const void*>(kern_ptr), smem, attr_done[bwd][la2][opt])) return ENF_ELAUNCH;
+    if (!enf_lds_attr(reinterpret_cast<const void*>(kern_ptr), smem, attr_done[wg ? 2 : bwd][la2][opt])) return ENF_ELAUNCH;
     hipLaunchKernelGGL(kern_ptr, grid, dim3(NTHREADS), smem, st, A);
     return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
   };
+  if (wg) {
+    if (la2) return opt ? go(enf_tail_bwd_kernel<D, H, BF16, true, false, true>) : go(enf_tail_bwd_kernel<D, H, BF16, true, true, true>);
+    return opt ? go(enf_tail_bwd_kernel<D, H, BF16, false, false, true>) : go(enf_tail_bwd_kernel<D, H, BF16, false, true, true>);
+  }
   if (bwd) {
     if (la2) return opt ? go(enf_tail_bwd_kernel<D, H, BF16, true, false>) : go(enf_tail_bwd_kernel<D, H, BF16, true, true>);
     return opt ? go(enf_tail_bwd_kernel<D, H, BF16, false, false>) : go(enf_tail_bwd_kernel<D, H, BF16, false, true>);
@@ -373,10 +412,19 @@ static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
   return opt ? go(enf_tail_fwd_kernel<D, H, BF16, false, true>) : go(enf_tail_fwd_kernel<D, H, BF16, false, false>);
 }
 
+extern "C" int enf_launch_tail_wg(const EnfDims& m, const EnfLayout& L, const char* blob, const float* ybar, float* out,
+                                  const float* dout, float* dybar, float* delta, float* act, float* tdel, int bwd, int opt, hipStream_t st);
 extern "C" int enf_launch_tail(const EnfDims& m, const EnfLayout& L, const char* blob, const float* ybar, float* out,
                                const float* dout, float* dybar, float* delta, float* act, int bwd, int opt, hipStream_t st) {
+  return enf_launch_tail_wg(m, L, blob, ybar, out, dout, dybar, delta, act, nullptr, bwd, opt, st);
+}
+// tdel != NULL (backward only): the weight-gradient form of the backward -- it also leaves every layer's input (in `act`, in place
+// of the pre-activations) and delta (in `tdel`) for the X^T delta products of enf_train.hip
+extern "C" int enf_launch_tail_wg(const EnfDims& m, const EnfLayout& L, const char* blob, const float* ybar, float* out,
+                                  const float* dout, float* dybar, float* delta, float* act, float* tdel, int bwd, int opt, hipStream_t st) {
   if (m.OB != 1) return ENF_EUNSUPPORTED;
   TailArgs A;
+  A.tdel = tdel;
   A.ybar = ybar; A.blob = blob; A.L = L; A.out = out; A.dout = dout; A.dybar = dybar; A.delta = delta; A.act = act;
   A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.Ht * m.Dt);
 #define ENF_CASE(DD, HH)                                                                   \

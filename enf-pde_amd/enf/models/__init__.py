@@ -322,6 +322,7 @@ class EquivariantCrossAttentionNeF:
         self._lt_held.clear()
         self._pair_key = None
         self._pair_blob = None
+        self._train_blob = None
 
     def load_params(self, tree, device="cuda"):
         """Build a parameter tree from nested numpy / torch arrays (e.g. an exported Flax tree)."""

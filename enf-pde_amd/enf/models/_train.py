@@ -302,6 +302,85 @@ W_NAMES = ["stem_w", "stem_b", "lna_g", "lna_b",
 assert len(W_NAMES) == _lib.ENF_NUM_TENSORS
 
 
+
+NATIVE_BACKWARD = True      # apply_train through ONE library call per direction (enf_forward_stages / enf_backward_all); False = the
+                            # older composition of differentiable device ops around the pair kernels (kept for the layered model and
+                            # as a cross-check in the tests)
+FROZEN = (W_NAMES.index("rq_coef"), W_NAMES.index("rv_coef"))      # RFF coefficients: no gradient (rff.py:87-90)
+
+
+class _TrainAllFunction(torch.autograd.Function):
+    """nef.apply differentiable w.r.t. all 46 weight tensors, the latents and the query coordinates: the forward is the library's
+    enf_forward_stages on the blob enf_pack_weights builds (folds included), the backward ONE call of enf_backward_all -- tail,
+    pair chain, prologue and the chain rule through the folds all inside the library (include/enf_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, x, p, a, sigma, model, key, *tensors):
+        lib = _lib.load()
+        B, Z, N, dev = p.shape[0], p.shape[1], x.shape[1], p.device
+        ctx.masks = getattr(model, "_masks", None)
+        desc = model._desc(B, N, Z, masks=ctx.masks)
+        xb, xstride = model._x_arg(x)
+        p_, a_ = p.detach().contiguous(), a.detach().contiguous()
+        s_ = sigma.detach().contiguous() if sigma is not None else None
+        st = _stream(dev)
+        ts = [t.detach().to(torch.float32).contiguous() for t in tensors]
+        hit = getattr(model, "_train_blob", None)
+        if key is not None and hit is not None and hit[0] == key:
+            blob, ts = hit[1], hit[2]
+        else:
+            blob = torch.empty(int(lib.enf_packed_weight_bytes(ctypes.byref(desc))), device=dev, dtype=torch.uint8)
+            arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            _lib.launch(dev, lib.enf_pack_weights, ctypes.byref(desc), arr, _ptr(blob), st)
+            if key is not None:
+                model._train_blob = (key, blob, ts)
+        HD = model._Hp * model._Dp
+        out = torch.empty((B, N, model.num_out), device=dev, dtype=torch.float32)
+        ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
+        lse = torch.empty((B, N, model._Hp), device=dev, dtype=torch.float32)
+        ws = model._workspace(desc, dev)
+        _lib.launch(dev, lib.enf_forward_stages, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(blob),
+                    _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16, st)          # prologue, fold, pair, tail + stash
+        ctx.ws_tag = model._ws_touch(ws)
+        ctx.model, ctx.xstride, ctx.dims, ctx.has_sigma = model, xstride, (B, N, Z), sigma is not None
+        ctx.x_shape = tuple(x.shape)
+        ctx.ts = ts                      # the fp32 sources the blob was packed from (the fold backward reads them)
+        ctx.save_for_backward(xb, p_, a_, s_ if s_ is not None else p_.new_empty(0), blob, ybar, lse)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        lib = _lib.load()
+        model = ctx.model
+        xb, p_, a_, s_, blob, ybar, lse = ctx.saved_tensors
+        sigma = s_ if ctx.has_sigma else None
+        B, N, Z = ctx.dims
+        dev = p_.device
+        st = _stream(dev)
+        read = ctx.masks is not None and ctx.masks[1] == "read"
+        desc = model._desc(B, N, Z, masks=ctx.masks) if read else model._desc(B, N, Z)
+        group = ctx.masks[2] if read else 1
+        cb = B
+        while cb > group and int(lib.enf_backward_all_scratch_bytes(ctypes.byref(desc), cb)) > STORE_BUDGET_BYTES:
+            cb = max(group, (cb - 1) // group * group)
+        nscr = int(lib.enf_backward_all_scratch_bytes(ctypes.byref(desc), cb))
+        scratch = torch.empty(nscr, device=dev, dtype=torch.uint8)
+        f32 = dict(device=dev, dtype=torch.float32)
+        grads = [None if i in FROZEN else torch.empty(t.shape, **f32) for i, t in enumerate(ctx.ts)]
+        arrT = (ctypes.c_void_p * len(ctx.ts))(*[t.data_ptr() for t in ctx.ts])
+        arrG = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
+        dp, da = torch.empty_like(p_), torch.empty_like(a_)
+        dsig = torch.empty((B, Z, 1), **f32)
+        dxq = torch.zeros((B, N, ctx.x_shape[-1]), **f32) if ctx.needs_input_grad[0] else None
+        ws = model._workspace(desc, dev)
+        flags = 3 if model._ws_tag(ws) == ctx.ws_tag else 0       # latent table + tail stash still the forward's
+        _lib.launch(dev, lib.enf_backward_all, ctypes.byref(desc), _ptr(xb), ctx.xstride, _ptr(p_), _ptr(a_), _ptr(sigma), arrT,
+                    _ptr(blob), _ptr(ybar), _ptr(lse), _ptr(dout.contiguous().float()), _ptr(dp), _ptr(da), _ptr(dsig), arrG, _ptr(dxq),
+                    _ptr(ws), ws.numel(), _ptr(scratch), nscr, flags, st)
+        model._ws_touch(ws)
+        return (dxq, dp, da, dsig if ctx.has_sigma else None, None, None, *grads)
+
 class _SelfAttnView:
     """The pair kernels' descriptor for a latent self-attention block: queries = the latents' own positions (and, for
     Ponita2D, orientations), the self-attention invariant (NEF:223-226)."""
@@ -363,6 +442,12 @@ def apply_layers(model, tensors, x, p, a, sigma):
 
 def apply_train(model, tensors, x, p, a, sigma):
     """nef.apply differentiable w.r.t. every weight tensor and the latents."""
+    if NATIVE_BACKWARD:
+        key = (model.precision, str(p.device), tuple((t.data_ptr(), t._version) for t in tensors))
+        if model._Dp != model.num_hidden or model._Hp != model.num_heads:  # run in the kernels' shape (differentiable zero padding)
+            tensors = _pad.pad_tensors(tensors, model.num_hidden, model._Dp, model.num_heads, model._Hp)
+        _lib.check(_lib.load().enf_check_desc(ctypes.byref(model._desc(p.shape[0], x.shape[1], p.shape[1]))))
+        return _TrainAllFunction.apply(x, p, a, sigma, model, key, *tensors)
     if model._Dp != model.num_hidden or model._Hp != model.num_heads:      # run in the kernels' shape (differentiable zero padding)
         tensors = _pad.pad_tensors(tensors, model.num_hidden, model._Dp, model.num_heads, model._Hp)
     W = dict(zip(W_NAMES, tensors))

@@ -341,6 +341,25 @@ int enf_ode_basis_backward(int64_t P, int I, int degree, int H1, int J, const fl
                            const float* W3, const float* b3, const float* dkb, float* dinv, float* dW1, float* db1,
                            float* dW3, float* db3, void* scratch, size_t scratch_bytes, void* stream);
 
+/* EVERY weight gradient in one call (value_and_grad over params['nef'], pde_trainer.py:255; SURVEY.md 8b's
+ * enf_backward_weights in full).  Given d out it returns d p, d a, d sigma AND the gradients of all ENF_NUM_TENSORS
+ * Flax-named tensors, fp32, shaped like the tensors enf_pack_weights takes, OVERWRITTEN (`dW` = host array of device pointers;
+ * the two frozen RFF coefficient entries -- rff.py:87-90 -- may be NULL, else they are zero-filled).  `tensors` are the same
+ * weights `packed` was built from (the fold backward needs the unfolded factors), `ybar` / `lse` come from enf_forward[_stages]
+ * on the same inputs, `workspace` is that call's workspace (flags: ENF_BWD_REUSE_PROLOGUE / ENF_BWD_REUSE_TAIL as for
+ * enf_backward_latents_ex; 0 recomputes what it needs), `dx` (B,N,dx) or NULL accumulates the gradient w.r.t. the queries.
+ * Kernels: the tail backward in its weight-gradient form, K3 with the activation store + K4 (enf_xtd_kernel), the prologue
+ * backward, fp32 matrix-pipe X^T delta products over the query / latent rows, and the chain rule through the folds of
+ * enf_pack_weights -- no library GEMM, no host framework op; slices are summed in a fixed order (same inputs, same bits,
+ * up to the float atomics of d lt).  scratch_bytes >= enf_backward_all_scratch_bytes(d, c) for some chunk size c in 1..B
+ * signals (the largest c that fits is used; with relu masks a multiple of mask_signals).  EnfDesc.mask_mode = ENF_MASK_READ
+ * replays the relu masks in the pair kernel as enf_backward_weights does. */
+size_t enf_backward_all_scratch_bytes(const EnfDesc* d, int chunk_signals);
+int enf_backward_all(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a, const float* sigma,
+                     const float* const* tensors, const void* packed, const float* ybar, const float* lse, const float* dout,
+                     float* dp, float* da, float* dsigma, float* const* dW, float* dx, void* workspace, size_t workspace_bytes,
+                     void* scratch, size_t scratch_bytes, unsigned flags, void* stream);
+
 /* Weight gradients of the per-pair chain (enf_backward_weights).  enf_pair_backward_ex plus, in the same
  * call, the gradients of the loss w.r.t. the ten trainable ENF_P_* tensors:
  *     dpair[ENF_P_A*] = X^T delta  (in, out),   dpair[ENF_P_B*] = 1^T delta      over all B Z N pairs, fp32, OVERWRITTEN

@@ -373,3 +373,28 @@ def _leaves_of(obj):
             yield from _leaves_of(v)
     else:
         yield obj.detach().cpu().numpy() if hasattr(obj, "detach") else obj
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_native_backward_matches_the_composed_path(cuda, precision, monkeypatch):
+    """enf_backward_all (tail, prologue and fold gradients inside the library) against the older composition of differentiable
+    device ops around the pair kernels: same 46 weight gradients and latent gradients (f32: rounding of different summation
+    orders; bf16: the tail's layer inputs are kept in fp32 by the library and rounded to bf16 by neither path's products)."""
+    from enf_pde_amd.enf.models import _train
+    cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=3, freq=(0.5, 1.0))
+    prm = R.init_params(9, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 3, 90, 11, 10)
+    w = np.random.default_rng(11).standard_normal((3, 90, 3))
+    res = {}
+    for native in (True, False):
+        monkeypatch.setattr(_train, "NATIVE_BACKWARD", native)
+        res[native] = hip(cuda, build_nef(cfg, precision), prm, x, p, a, s, w)
+    tol = 2e-5 if precision == "f32" else 2e-2
+    assert np.abs(res[True][0] - res[False][0]).max() <= tol * np.abs(res[False][0]).max()
+    gmax = max(np.linalg.norm(g) for g in res[False][1])
+    for path, g1, g0 in zip(TENSOR_PATHS, res[True][1], res[False][1]):
+        n0 = np.linalg.norm(g0)
+        err = np.linalg.norm(g1 - g0) / (n0 if n0 > 1e-6 * gmax else gmax)
+        assert err < 10 * tol, ("/".join(path), err)
+    for k in (2, 3, 4):
+        assert np.linalg.norm(res[True][k] - res[False][k]) <= 10 * tol * max(np.linalg.norm(res[False][k]), 1e-12)
