@@ -80,6 +80,9 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 // waves per workgroup: the z-fold variant runs TWO independent 4-wave workgroups per CU (one wave of each
 // per SIMD) so that the SIMD-mates never meet at a barrier: while one computes its MFMA stage the other
 // keeps the vector ALU busy (8-wave lockstep measured 2 V + M per stage, M = the younger wave's MFMAs).
+#ifndef ENF_K2_INV_SPECIALISED
+#define ENF_K2_INV_SPECIALISED 1
+#endif
 template <bool ZFOLD> struct PairWaves { static constexpr int NW = ZFOLD && ENF_ZFOLD_WAVES == 4 ? 4 : NWAVES; };
 
 template <int D, int H, bool BF16, int NW> struct PairSmem {
@@ -96,8 +99,12 @@ template <int D, int H, bool BF16, int NW> struct PairSmem {
 // ZFOLD: qg = 8 (every wave walks all latents, the 8 waves in step), and per head the gamma/beta GEMM, FiLM
 // and the mixer's first Dense are ONE D x D GEMM with the per-latent matrix W_zh of enf_wz.hip:
 //   a5_h = W_zh^T n + c_zh      (5 D x D GEMMs per pair instead of 9 D x D equivalents)
-template <int D, int H, bool BF16, bool ZFOLD, bool MASKS>
+// INV >= 0: the invariant as a compile-time constant (the shipped configs' instantiations, launch code below): the per-latent step then
+// carries no switch over the invariant (as in K3, enf_pair_bwd.hip)
+template <int D, int H, bool BF16, bool ZFOLD, bool MASKS, int INV = -1>
 __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_kernel(PairFwdArgs A) {
+  const int inv_id = INV >= 0 ? INV : A.inv;
+  const int dx_ = INV >= 0 ? 2 : A.dx;
   using Cfg = PairCfg<D, BF16>;
   constexpr int NW = PairWaves<ZFOLD>::NW, NTH = 64 * NW;
   using SM = PairSmem<D, H, BF16, NW>;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   for (int i = tid; i < 2 * H * D; i += NTH) c_bgb[i] = G(A.L.bgb)[i];
   for (int i = tid; i < 2 * D; i += NTH) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
 
-  const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * A.dx, A.dx, A.inv);
+  const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * dx_, dx_, inv_id);
   const unsigned pQ1 = (unsigned)A.L.aq1, pV1 = (unsigned)A.L.av1, pF = (unsigned)A.L.af, pGB = (unsigned)A.L.agb, pM = (unsigned)A.L.am;
 
   Pipe P;
@@ -187,8 +194,8 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     float inv[4], win;
-    const bool has_ph = D == 64 && enf_inv_has_phase(A.inv);   // ball / ball_lat (64-wide only): rotation matrix and RFF phases of the latent
-    pair_invariant<BF16>(A.inv, A.dx, q, pz, wcoef, A.use_window, inv, win, ltrow + enf_lt_off_ext(H, D));
+    const bool has_ph = INV < 0 && D == 64 && enf_inv_has_phase(inv_id);   // ball / ball_lat (64-wide only): rotation matrix and RFF phases of the latent
+    pair_invariant<BF16>(inv_id, dx_, q, pz, wcoef, A.use_window, inv, win, ltrow + enf_lt_off_ext(H, D));
 
     float logit[H];
     Frags<BF16, KB> F;
@@ -399,14 +406,14 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   }
 }
 
-template <int D, int H, bool BF16, bool ZFOLD, bool MASKS = false>
+template <int D, int H, bool BF16, bool ZFOLD, bool MASKS = false, int INV = -1>
 static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   if constexpr (!MASKS) {
-    if (A.mask_mode) return launch_pair_fwd<D, H, BF16, ZFOLD, true>(A, st);
+    if (A.mask_mode) return launch_pair_fwd<D, H, BF16, ZFOLD, true>(A, st);       // (the masked passes keep the run-time invariant)
   }
   constexpr int NW = PairWaves<ZFOLD>::NW;
   using SM = PairSmem<D, H, BF16, NW>;
-  auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD, MASKS>;
+  auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD, MASKS, INV>;
   static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
   if (!enf_lds_attr(reinterpret_cast<const void*>(kern), SM::TOTAL, attr_done)) return ENF_ELAUNCH;
   dim3 grid((A.N + 16 * A.qg - 1) / (16 * A.qg), A.B);
@@ -445,6 +452,19 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
     if (zfold) return m.bf16 ? launch_pair_fwd<DD, HH, true, true>(A, st) : launch_pair_fwd<DD, HH, false, true>(A, st); \
     return m.bf16 ? launch_pair_fwd<DD, HH, true, false>(A, st) : launch_pair_fwd<DD, HH, false, false>(A, st);         \
   }
+#if ENF_K2_INV_SPECIALISED
+  if (m.bf16 && m.dx == 2 && !A.mask_mode) {       // the shipped configs' bf16 kernels with the invariant fixed at compile time
+    if (m.D == 128 && m.H == 2) {
+#define ENF_SPEC(INVID)                                                                                                  \
+      if (m.inv == INVID) return zfold ? launch_pair_fwd<128, 2, true, true, false, INVID>(A, st)                          \
+                                       : launch_pair_fwd<128, 2, true, false, false, INVID>(A, st);
+      ENF_SPEC(ENF_INV_REL_POS_PERIODIC) ENF_SPEC(ENF_INV_LATITUDE_PERIODIC) ENF_SPEC(ENF_INV_POLAR_PERIODIC)
+#undef ENF_SPEC
+    }
+    if (m.D == 64 && m.H == 2 && m.inv == ENF_INV_PONITA)
+      return zfold ? launch_pair_fwd<64, 2, true, true, false, ENF_INV_PONITA>(A, st) : launch_pair_fwd<64, 2, true, false, false, ENF_INV_PONITA>(A, st);
+  }
+#endif
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)

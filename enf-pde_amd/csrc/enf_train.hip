@@ -33,7 +33,8 @@ typedef float tf4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------ X^T Y over long row axes
 // part[s][k][n] = sum_{r in slice s} X[r][k] Y[r][n]     (K x N tile of 64 x 64 per workgroup, 16 x 64 per wave)
 // v_mfma_f32_16x16x4_f32: A[i][kk] = X[r0 + kk][k0 + i] (lane: i = lane & 15, kk = lane >> 4), B[kk][j] = Y[r0 + kk][n0 + j].
-constexpr int XT_ROWS = 16;       // rows per unrolled step (4 MFMA k-steps of 4 rows)
+constexpr int XT_ROWS = 32;       // rows per unrolled step (8 MFMA k-steps of 4 rows: 8 + 32 loads in flight per lane)
+constexpr int XT_U = XT_ROWS / 4;
 __global__ __launch_bounds__(256) void enf_rows_xty_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ Y,
                                                           long long ldy, long long R, int K, int N, long long rows_per_slice,
                                                           float* __restrict__ part) {
@@ -49,9 +50,9 @@ __global__ __launch_bounds__(256) void enf_rows_xty_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < 4; ++t) nok[t] = n0 + 16 * t + i < N;
   for (long long r0 = r_lo; r0 < r_hi; r0 += XT_ROWS) {
-    float xa[4], yb[4][4];
+    float xa[XT_U], yb[XT_U][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < XT_U; ++u) {
       const long long r = r0 + 4 * u + q;
       const bool rok = r < r_hi;
       xa[u] = rok && kok ? X[r * ldx + k0 + i] : 0.f;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void enf_rows_xty_kernel(const float* __restri
       for (int t = 0; t < 4; ++t) yb[u][t] = rok && nok[t] ? Y[r * ldy + n0 + 16 * t + i] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < XT_U; ++u)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u], yb[u][t], acc[t], 0, 0, 0);
   }
@@ -81,29 +82,30 @@ __global__ void enf_slices_sum_kernel(const float* __restrict__ part, int S, lon
   for (int z = 0; z < S; ++z) s += part[(size_t)z * KN + e];
   out[e] = acc ? out[e] + alpha * s : alpha * s;
 }
-// out[n] = sum_r Y[r][n] (* X[r][n] if X): one workgroup per 64 columns, 4 row groups, fixed order
+// part[s][n] = sum_{r in slice s} Y[r][n] (* X[r][n] if X): 64 columns x 4 row groups per workgroup, slices summed afterwards in a
+// fixed order (enf_slices_sum_kernel)
 __global__ __launch_bounds__(256) void enf_rows_colsum_kernel(const float* __restrict__ Y, long long ldy, const float* __restrict__ X,
-                                                             long long ldx, long long R, int N, float* __restrict__ out, float alpha, int acc) {
+                                                             long long ldx, long long R, int N, long long rows_per_slice,
+                                                             float* __restrict__ part) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
+  const long long r_lo = (long long)blockIdx.y * rows_per_slice;
+  const long long r_hi = r_lo + rows_per_slice < R ? r_lo + rows_per_slice : R;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (n < N) {
-    long long r = g;
-    for (; r + 12 < R; r += 16) {
+    long long r = r_lo + g;
+    for (; r + 12 < r_hi; r += 16) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long rr = r + 4 * u;
         s[u] += X ? Y[rr * ldy + n] * X[rr * ldx + n] : Y[rr * ldy + n];
       }
     }
-    for (; r < R; r += 4) s[0] += X ? Y[r * ldy + n] * X[r * ldx + n] : Y[r * ldy + n];
+    for (; r < r_hi; r += 4) s[0] += X ? Y[r * ldy + n] * X[r * ldx + n] : Y[r * ldy + n];
   }
   red[g][c] = (s[0] + s[1]) + (s[2] + s[3]);
   __syncthreads();
-  if (g == 0 && n < N) {
-    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    out[n] = acc ? out[n] + alpha * t : alpha * t;
-  }
+  if (g == 0 && n < N) part[(size_t)blockIdx.y * N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // ------------------------------------------------------------------------------------------------ small dense helpers (weight space)
@@ -177,7 +179,12 @@ struct Ctx {
   }
   void colsum(const float* Y, long long ldy, long long R, int N, float* out, const float* X = nullptr, long long ldx = 0, float alpha = 1.f, int acc = 0) {
     if (rc) return;
-    hipLaunchKernelGGL(enf_rows_colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, Y, ldy, X, ldx, R, N, out, alpha, acc);
+    long long S = (R + 255) / 256;
+    if (S > 64) S = 64;
+    const long long rps = (R + S - 1) / S;
+    S = (R + rps - 1) / rps;
+    hipLaunchKernelGGL(enf_rows_colsum_kernel, dim3((N + 63) / 64, (unsigned)S), dim3(256), 0, st, Y, ldy, X, ldx, R, N, rps, part);
+    hipLaunchKernelGGL(enf_slices_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, (int)S, (long long)N, out, alpha, acc);
     chk();
   }
   void gemm(float* C, int ldc, const float* A, int lda, int ta, const float* B, int ldb, int tb, int M, int N, int K, float alpha = 1.f, int acc = 0) {

@@ -303,7 +303,7 @@ assert len(W_NAMES) == _lib.ENF_NUM_TENSORS
 
 
 
-NATIVE_BACKWARD = True      # apply_train through ONE library call per direction (enf_forward_stages / enf_backward_all); False = the
+NATIVE_BACKWARD = __import__("os").environ.get("ENF_TRAIN_COMPOSED") != "1"      # apply_train through ONE library call per direction (enf_forward_stages / enf_backward_all); False = the
                             # older composition of differentiable device ops around the pair kernels (kept for the layered model and
                             # as a cross-check in the tests)
 FROZEN = (W_NAMES.index("rq_coef"), W_NAMES.index("rv_coef"))      # RFF coefficients: no gradient (rff.py:87-90)
