@@ -93,7 +93,7 @@ def pair_flops_per_query(z=Z, d=D, h=H, i=4):
 
 
 # D x D MFMA GEMMs a pair kernel issues per pair (counted from the kernels at H = 2): executed FLOPs = units * 2 D^2
-MFMA_UNITS = {("fwd", "z_fold"): lambda h: 3 + h, ("fwd", "latent_split"): lambda h: 3 + 3 * h,
+MFMA_UNITS = {("fwd", "z_fold"): lambda h: 3 + h, ("fwd", "z_fold_zsplit"): lambda h: 3 + h, ("fwd", "latent_split"): lambda h: 3 + 3 * h,
               ("bwd", "z_fold"): lambda h: 16 if h == 2 else None, ("bwd", "latent_split"): lambda h: 24 if h == 2 else None}
 
 
@@ -362,7 +362,7 @@ def pair_kernel_rooflines(c, m, device, iters=20):
                                                                P(ybar), P(lse), P(ws), ws.numel(), stages, st))
         fwd(1 | 8 | 2 | 4 | 16)      # prologue, fold, pair, tail (+ stash): the workspace now holds what PAIR alone reuses
         ms = _time_launches(lambda: fwd(2), device, iters)
-        variant = {1: "latent_split", 2: "z_fold"}[lib.enf_pair_variant(ctypes.byref(desc), 0)]
+        variant = {1: "latent_split", 2: "z_fold", 3: "z_fold_zsplit"}[lib.enf_pair_variant(ctypes.byref(desc), 0)]
         pairs = bb * n * z
         rec = lambda kernel, kind, var, ms_, mult, calls: {
             "kernel": kernel, "shape": {"signals": bb, "queries": n, "latents": z}, "variant": var, "launch_ms": round(ms_, 4),

@@ -41,7 +41,7 @@ class EnfDesc(ctypes.Structure):
                 ("mask_signals", ctypes.c_int32), ("reserved", ctypes.c_int32), ("relu_masks", ctypes.c_void_p)]
 
 
-VARIANT = {"auto": 0, "latent_split": 1, "z_fold": 2}       # ENF_VARIANT_*
+VARIANT = {"auto": 0, "latent_split": 1, "z_fold": 2, "z_fold_zsplit": 3}       # ENF_VARIANT_*
 MASK_MODE = {"off": 0, "write": 1, "read": 2}                # ENF_MASK_*
 
 

@@ -13,7 +13,7 @@ int enf_launch_prologue(const EnfDims&, const EnfLayout&, const char*, const flo
 int enf_launch_prologue_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, const float*,
                             const float*, const float*, float*, float*, float*, hipStream_t);
 int enf_launch_pair_fwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, float*, float*,
-                        char*, float*, char*, int, int, hipStream_t);
+                        char*, float*, char*, float*, int, int, hipStream_t);
 int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const float*, long long, const float*, const float*,
                         const float*, const float*, float*, void* const*, const char*, const float*, float*, hipStream_t);
 int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
@@ -67,7 +67,7 @@ extern "C" int enf_check_desc(const EnfDesc* d) {
   if (d->h_true < 0 || d->h_true > d->H) return ENF_EINVAL;
   if (d->O > 32) return ENF_EUNSUPPORTED;
   if (d->precision != ENF_PREC_F32 && d->precision != ENF_PREC_BF16) return ENF_EINVAL;
-  if (d->pair_fwd_variant < ENF_VARIANT_AUTO || d->pair_fwd_variant > ENF_VARIANT_ZFOLD) return ENF_EINVAL;
+  if (d->pair_fwd_variant < ENF_VARIANT_AUTO || d->pair_fwd_variant > ENF_VARIANT_ZFOLD_ZSPLIT) return ENF_EINVAL;
   if (d->pair_bwd_variant < ENF_VARIANT_AUTO || d->pair_bwd_variant > ENF_VARIANT_ZFOLD) return ENF_EINVAL;
   if (d->mask_mode < ENF_MASK_OFF || d->mask_mode > ENF_MASK_READ || d->mask_signals < 0) return ENF_EINVAL;
   if (d->mask_mode != ENF_MASK_OFF && !d->relu_masks) return ENF_EINVAL;
@@ -172,7 +172,8 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
   if ((stages & ENF_STAGE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
   if ((stages & (ENF_STAGE_PAIR | ENF_STAGE_FOLD)) &&
       (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
-                                zf ? ws + W.wzu : nullptr, (stages & ENF_STAGE_FOLD) != 0, (stages & ENF_STAGE_PAIR) != 0, st)))
+                                zf ? ws + W.wzu : nullptr, enf_zfold_split(m) > 1 ? F(W.ysplit) : nullptr, (stages & ENF_STAGE_FOLD) != 0,
+                                (stages & ENF_STAGE_PAIR) != 0, st)))
     return rc;
   if ((stages & ENF_STAGE_PREPARE_BWD) && enf_use_zfold_bwd(m)) {
     // what the backward needs from the latent table alone -- its per-latent folded matrices, the zeroed gradient table --
@@ -314,7 +315,9 @@ extern "C" int enf_pair_variant(const EnfDesc* d, int backward) {
   const int rc = enf_check_desc(d);
   if (rc) return rc;
   const EnfDims m = enf_dims(d);
-  return (backward ? enf_use_zfold_bwd(m) : enf_use_zfold(m)) ? ENF_VARIANT_ZFOLD : ENF_VARIANT_LATENT_SPLIT;
+  if (backward) return enf_use_zfold_bwd(m) ? ENF_VARIANT_ZFOLD : ENF_VARIANT_LATENT_SPLIT;
+  const int sp = enf_zfold_split(m);
+  return sp > 1 ? ENF_VARIANT_ZFOLD_ZSPLIT : (sp == 1 ? ENF_VARIANT_ZFOLD : ENF_VARIANT_LATENT_SPLIT);
 }
 
 extern "C" size_t enf_pair_scratch_bytes(const EnfDesc* d) {
@@ -322,7 +325,8 @@ extern "C" size_t enf_pair_scratch_bytes(const EnfDesc* d) {
   const EnfDims m = enf_dims(d);
   if (!enf_use_zfold(m)) return 0;
   return enf_align((size_t)m.B * m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16)) +
-         enf_align(sizeof(float) * (size_t)m.B * m.Z * m.HD) + (size_t)m.B * m.Z * enf_wzu_bytes(m.H, m.D);
+         enf_align(sizeof(float) * (size_t)m.B * m.Z * m.HD) + enf_align((size_t)m.B * m.Z * enf_wzu_bytes(m.H, m.D)) +
+         (enf_zfold_split(m) > 1 ? sizeof(float) * enf_zfold_split(m) * ((size_t)m.B * m.N * m.HD + (size_t)m.B * m.N * m.H * 3) : 0);
 }
 
 extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float* lt, const void* packed,
@@ -336,7 +340,8 @@ extern "C" int enf_pair_forward(const EnfDesc* d, const float* x, int64_t x_bstr
   char* wz = need ? (char*)scratch : nullptr;
   float* wzb = need ? reinterpret_cast<float*>(wz + enf_align((size_t)m.B * m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16))) : nullptr;
   char* wzu = need ? reinterpret_cast<char*>(wzb) + enf_align(sizeof(float) * (size_t)m.B * m.Z * m.HD) : nullptr;
-  return enf_launch_pair_fwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, ybar, lse, wz, wzb, wzu, 1, 1,
+  float* ysplit = need && enf_zfold_split(m) > 1 ? reinterpret_cast<float*>(wzu + enf_align((size_t)m.B * m.Z * enf_wzu_bytes(m.H, m.D))) : nullptr;
+  return enf_launch_pair_fwd(m, enf_layout(m), (const char*)packed, x, x_bstride, lt, ybar, lse, wz, wzb, wzu, ysplit, 1, 1,
                              (hipStream_t)stream);
 }
 

@@ -197,15 +197,34 @@ ENF_HD inline int enf_lt_off_c(int H, int D) { return 2 * H * D + 8; }
 // EnfDesc.pair_fwd_variant forces the choice per call; ENF_VARIANT_AUTO is the heuristic below, a function of the shape
 // alone (only an -DENF_AB_SWITCHES build of the library lets ENF_ZFOLD=0 / 1 in the environment replace it).
 int enf_zfold_env(int backward);   // enf_api.hip: -1 (always, in the product library), 0 / 1
-inline bool enf_use_zfold(const EnfDims& m) {
+// 0 = the latent-split kernel; s >= 1 = the z-fold kernel with every signal's latents split over s workgroups per 128-query tile
+// (s > 1 = ENF_VARIANT_ZFOLD_ZSPLIT: partial softmax sums, merged by enf_zsplit_merge_kernel).  AUTO splits when the 128-query
+// workgroups alone would under-fill the chip (< 192) and there are >= 128 latents: the split that minimises the number of
+// workgroup ROUNDS on 256 CUs per unit of work, rounds(wgs s) / s (+ 3 % per extra split for the per-workgroup prologue and the
+// merge), with >= 32 latents per workgroup and >= 192 workgroups in all -- 128 tiles -> 2 x (one round of 256), 144 tiles -> 3 x
+// (432 workgroups, two rounds of a third each: 0.67 of the unsplit time; 2 x would be 288 workgroups = two rounds of a half).
+constexpr int ENF_ZSPLIT_MAX = 4;
+inline int enf_zfold_split(const EnfDims& m) {
   // one signal's folded matrices sit behind a buffer resource with 32-bit offsets: beyond 2 GB per signal (Z >= 32768
   // at D = 128, H = 2) only the latent-split variant can run
-  if ((long long)m.Z * m.H * (long long)m.D * m.D * (m.bf16 ? 2 : 4) >= 0x7fffffffLL) return false;
-  if (m.var_fwd != ENF_VARIANT_AUTO) return m.var_fwd == ENF_VARIANT_ZFOLD;
+  if ((long long)m.Z * m.H * (long long)m.D * m.D * (m.bf16 ? 2 : 4) >= 0x7fffffffLL) return 0;
+  if (m.var_fwd == ENF_VARIANT_ZFOLD_ZSPLIT) return m.Z >= 2 ? 2 : 1;
+  if (m.var_fwd != ENF_VARIANT_AUTO) return m.var_fwd == ENF_VARIANT_ZFOLD ? 1 : 0;
   const int mode = enf_zfold_env(0);
-  if (mode >= 0) return mode == 1;
-  return (long long)((m.N + 127) / 128) * m.B >= 192;
+  if (mode >= 0) return mode;
+  const long long wgs = (long long)((m.N + 127) / 128) * m.B;
+  if (wgs >= 192) return 1;
+  if (m.Z < 128) return 0;
+  int best = 0;
+  double best_cost = 0.8;            // below this fraction of the unsplit z-fold time the split pays against the latent-split kernel
+  for (int s = 2; s <= ENF_ZSPLIT_MAX; ++s) {
+    if (m.Z / s < 32 || wgs * s < 192) continue;
+    const double cost = (double)((wgs * s + 255) / 256) / s * (1.0 + 0.03 * (s - 1));
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
 }
+inline bool enf_use_zfold(const EnfDims& m) { return enf_zfold_split(m) > 0; }
 
 ENF_HD inline size_t enf_wzu_bytes(int H, int D) { return (size_t)(D / 32) * 4 * H * 16; }
 
@@ -233,6 +252,7 @@ struct EnfWorkspace {
   size_t wzb;       // B*Z*H*D floats: their bias vectors
   size_t wzt;       // B*Z*H x [forward | backward] packed D x D panels of W_zh (z-fold backward)
   size_t wzu;       // B*Z x (D/32 * 4 * H) x 16 B: the logit vectors u_zh as bf16 A-operand rows (z-fold, bf16 mode)
+  size_t ysplit;    // ENF_VARIANT_ZFOLD_ZSPLIT (s splits): s x B*N*HD partial weighted sums | s x B*N*H x 3 softmax statistics (m, l, c)
   size_t total;
 };
 
@@ -256,6 +276,7 @@ inline EnfWorkspace enf_workspace(const EnfDims& m) {
   W.wzb = take(zf || zb ? f * BZ * m.HD : 0);
   W.wzt = take(zb ? BZ * m.H * 2 * enf_panel_bytes(m.D, m.D, m.bf16) : 0);
   W.wzu = take(zf ? BZ * enf_wzu_bytes(m.H, m.D) : 0);
+  W.ysplit = take(enf_zfold_split(m) > 1 ? f * enf_zfold_split(m) * (BN * m.HD + BN * m.H * 3) : 0);
   W.total = o;
   return W;
 }

@@ -32,6 +32,8 @@ struct PairFwdArgs {
   int xcd_remap;                          // z-fold: 1 when B % 8 == 0 (see the kernel)
   unsigned* masks; int mask_mode, mask_B; // relu masks (ENF_MASK_*): buffer, 0 off / 1 write / 2 read, signals per mask set
   int B, N, Z, dx, inv, use_window, qg;   // qg: query groups per workgroup (1,2,4,8); ZS = 8/qg
+  int zsplit;                             // z-fold: workgroups per query tile (grid.z), each walks Z / zsplit latents (ENF_VARIANT_ZFOLD_ZSPLIT)
+  float* ysplit;                          // zsplit > 1: [zsplit][B N HD] partial sums | [zsplit][B N H][3] (m, l, c), merged by enf_zsplit_merge_kernel
 };
 
 // Debug build only (-DENF_STAMPS): s_memtime stamps of the first iterations of workgroup 0, one row per
@@ -164,9 +166,12 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   }
 
   const int ltstride = enf_lt_stride(H, D);
-  const int iters = (A.Z + ZS - 1) / ZS;
+  // z-fold with zsplit > 1: this workgroup walks the latents [z_lo, z_lo + iters) of its signal and leaves PARTIAL sums
+  const int zchunk = ZFOLD ? (A.Z + A.zsplit - 1) / A.zsplit : 0;
+  const int z_lo = ZFOLD ? (int)blockIdx.z * zchunk : 0;
+  const int iters = ZFOLD ? max(0, min(A.Z, z_lo + zchunk) - z_lo) : (A.Z + ZS - 1) / ZS;
   for (int it = 0; it < iters; ++it) {
-    const int z = it * ZS + zs;
+    const int z = ZFOLD ? z_lo + it : it * ZS + zs;
     const bool active = z < A.Z;
     const float* ltrow = A.lt + ((size_t)b * A.Z + (active ? z : A.Z - 1)) * ltstride;
     STAMP(0);
@@ -337,6 +342,22 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   }
 
   pipe_finish(P);
+  if constexpr (ZFOLD) {
+    if (A.zsplit > 1) {        // partial weighted sums against this workgroup's own reference logit + (m, l, c): merged afterwards
+      if (n0 + col < A.N) {
+        const size_t BN = (size_t)A.B * A.N, row = (size_t)b * A.N + n0 + col;
+        float* yo = A.ysplit + ((size_t)blockIdx.z * BN + row) * (H * D);
+        float* so = A.ysplit + (size_t)A.zsplit * BN * (H * D) + ((size_t)blockIdx.z * BN + row) * (H * 3);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(yo + h * D + 16 * t + 4 * quad) = Y[h][t];
+          if (quad == 0) { so[h * 3] = iters > 0 ? sm_m[h] : -INFINITY; so[h * 3 + 1] = sm_l[h]; so[h * 3 + 2] = sm_c[h]; }
+        }
+      }
+      return;
+    }
+  }
   // ---- combine the ZS latent splits of each query group (all staging is finished: ring is free)
   if (quad == 0) {
 #pragma unroll
@@ -406,6 +427,30 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   }
 }
 
+// ENF_VARIANT_ZFOLD_ZSPLIT: ybar[row][h][:] = sum_s e^{m_s - m*} Y_s / L - C / L,  lse = m* + log L  with  L = sum_s e^{m_s - m*} l_s (C alike):
+// exactly the in-kernel combine of the latent-split variant, across workgroups.  One thread per (row, feature).
+__global__ __launch_bounds__(256) void enf_zsplit_merge_kernel(const float* __restrict__ ysplit, int S, long long BN, int H, int D,
+                                                              float* __restrict__ ybar, float* __restrict__ lse) {
+  const int HD = H * D;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= BN * HD) return;
+  const long long row = e / HD;
+  const int c = (int)(e % HD), h = c / D;
+  const float* st = ysplit + (size_t)S * BN * HD;
+  float ms = -INFINITY;
+  for (int s = 0; s < S; ++s) ms = fmaxf(ms, st[((size_t)s * BN + row) * (H * 3) + h * 3]);
+  float L = 0.f, C = 0.f, y = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* q = st + ((size_t)s * BN + row) * (H * 3) + h * 3;
+    const float aw = __expf(q[0] - ms);          // exp(-inf) = 0: a split that saw no latent
+    L = fmaf(aw, q[1], L);
+    C = fmaf(aw, q[2], C);
+    y = fmaf(aw, ysplit[((size_t)s * BN + row) * HD + c], y);
+  }
+  ybar[(size_t)row * HD + c] = (y - C) / L;
+  if (c % D == 0) lse[(size_t)row * H + h] = ms + __logf(L);
+}
+
 template <int D, int H, bool BF16, bool ZFOLD, bool MASKS = false, int INV = -1>
 static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   if constexpr (!MASKS) {
@@ -416,8 +461,13 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD, MASKS, INV>;
   static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
   if (!enf_lds_attr(reinterpret_cast<const void*>(kern), SM::TOTAL, attr_done)) return ENF_ELAUNCH;
-  dim3 grid((A.N + 16 * A.qg - 1) / (16 * A.qg), A.B);
+  dim3 grid((A.N + 16 * A.qg - 1) / (16 * A.qg), A.B, ZFOLD ? A.zsplit : 1);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), SM::TOTAL, st, A);
+  if (ZFOLD && A.zsplit > 1) {
+    const long long BN = (long long)A.B * A.N, tot = BN * H * D;
+    hipLaunchKernelGGL(enf_zsplit_merge_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)A.ysplit, A.zsplit, BN, H, D,
+                       A.ybar, A.lse);
+  }
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
 
@@ -427,7 +477,7 @@ extern "C" int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, cons
 // relu masks: per call (EnfDims.masks / mask_mode / mask_B, from the descriptor)
 
 extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const char* blob, const float* x, long long x_bstride,
-                                   const float* lt, float* ybar, float* lse, char* wz, float* wzb, char* wzu,
+                                   const float* lt, float* ybar, float* lse, char* wz, float* wzb, char* wzu, float* ysplit,
                                    int run_fold, int run_pair, hipStream_t st) {
   PairFwdArgs A;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu; A.inv_d = 1.0f / (float)m.Dt;
@@ -438,7 +488,9 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;
   A.qg = NWAVES / zs;
   const bool zfold = wz && wzb && wzu && (size_t)m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
-  A.xcd_remap = zfold && m.B % 8 == 0;
+  A.zsplit = zfold && ysplit && enf_zfold_split(m) > 1 ? enf_zfold_split(m) : 1;
+  A.ysplit = ysplit;
+  A.xcd_remap = zfold && m.B % 8 == 0;        // (grid.z slabs keep the residue: gridDim.x * B is a multiple of 8 then)
   if (zfold) {
     A.qg = PairWaves<true>::NW;
     if (run_fold) {

@@ -59,7 +59,11 @@ enum {
 enum {
   ENF_VARIANT_AUTO = 0,          /* by problem size */
   ENF_VARIANT_LATENT_SPLIT = 1,  /* forward: the 8 waves split Z; backward: one wave = one latent */
-  ENF_VARIANT_ZFOLD = 2          /* forward: >= 192 workgroups of 128 queries; backward: >= 192 latents */
+  ENF_VARIANT_ZFOLD = 2,         /* forward: >= 192 workgroups of 128 queries; backward: >= 192 latents */
+  ENF_VARIANT_ZFOLD_ZSPLIT = 3   /* forward only: the z-fold kernel with every signal's latents split over 2-4 workgroups per 128 queries
+                                    (partial softmax sums merged by a small kernel; forced: 2): AUTO picks the split that fills 256 CUs
+                                    in the fewest rounds when fewer than 192 such workgroups exist and Z >= 128 -- e.g. 128 latents
+                                    on a 96 x 48 sphere grid, 4 signals: 144 workgroups -> 3 x 144 */
 };
 
 /* relu masks of a call (see "Relu masks" below) */
@@ -377,7 +381,8 @@ int enf_backward_weights(const EnfDesc* d, const float* x, int64_t x_bstride, co
                          float* dx, void* scratch, size_t scratch_bytes, void* stream);
 
 /* The pair-kernel variant a call with this descriptor runs (ENF_VARIANT_AUTO resolved): ENF_VARIANT_LATENT_SPLIT or
- * ENF_VARIANT_ZFOLD; `backward` = 0 for the forward kernel, 1 for the backward kernel.  Negative ENF_E* on a bad descriptor. */
+ * ENF_VARIANT_ZFOLD (or, forward only, ENF_VARIANT_ZFOLD_ZSPLIT); `backward` = 0 for the forward kernel, 1 for the backward kernel.
+ * Negative ENF_E* on a bad descriptor. */
 int enf_pair_variant(const EnfDesc* d, int backward);
 
 #ifdef __cplusplus

@@ -20,9 +20,9 @@ def cuda():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["latent_split", "z_fold"])
+@pytest.fixture(params=["latent_split", "z_fold", "z_fold_zsplit"])
 def pair_variant(request):
-    """Runs a test under both forward pair-kernel variants (EnfDesc.pair_fwd_variant, include/enf_hip.h)."""
+    """Runs a test under every forward pair-kernel variant (EnfDesc.pair_fwd_variant, include/enf_hip.h)."""
     from enf_pde_amd.enf.models import EquivariantCrossAttentionNeF as NeF
     prev = NeF.default_pair_variants
     NeF.default_pair_variants = (request.param, prev[1])

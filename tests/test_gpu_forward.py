@@ -75,12 +75,41 @@ def test_variants_agree_at_full_size(cuda, precision):
     params = nef.load_params(prm, device=cuda)
     t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
     outs = []
-    for mode in ("latent_split", "z_fold"):
+    for mode in ("latent_split", "z_fold", "z_fold_zsplit"):
         nef.pair_variants = (mode, "auto")
         outs.append(nef.apply(params, t(x), t(p), t(a), t(s)))
-    ref, got = outs
-    err = float((got - ref).abs().max() / ref.abs().max())
-    assert torch.isfinite(got).all() and err < (2e-5 if precision == "f32" else 3e-2), err
+    ref = outs[0]
+    for got in outs[1:]:
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert torch.isfinite(got).all() and err < (2e-5 if precision == "f32" else 3e-2), err
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_config3_decode_shape_picks_the_split_z_fold_and_agrees(cuda, precision):
+    """BASELINE config 3's decode (4 signals x 96 x 48 sphere grid, 128 latents: 144 workgroups of 128 queries on 256 CUs): AUTO now
+    resolves to the z-fold kernel with the latents split over two workgroups per query tile (ENF_VARIANT_ZFOLD_ZSPLIT, 288
+    workgroups); it must agree with the latent-split kernel there, and the latent gradients through it with the ones through
+    the latent-split forward (the backward reads the forward's lse)."""
+    import ctypes
+    from enf_pde_amd import _lib
+    cfg = make_cfg("latitude_periodic", D=128, H=2, C=32, O=3, freq=(0.05, 0.2))
+    prm = R.init_params(31, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 4, 96 * 48, 128, 32)
+    nef = build_nef(cfg, precision)
+    nef.pair_variants = ("auto", "auto")
+    assert _lib.load().enf_pair_variant(ctypes.byref(nef._desc(4, 96 * 48, 128)), 0) == 3
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    res = []
+    for mode in ("latent_split", "auto"):
+        nef.pair_variants = (mode, "auto")
+        tp, ta = t(p, True), t(a, True)
+        out = nef.apply(params, t(x), tp, ta, t(s))
+        out.square().sum().backward()
+        res.append((out.detach(), tp.grad, ta.grad))
+    tol = 2e-5 if precision == "f32" else 3e-2
+    for r, g in zip(res[0], res[1]):
+        assert torch.isfinite(g).all() and float((g - r).abs().max() / r.abs().max()) < (tol if r is res[0][0] else 20 * tol)
 
 
 def test_full_size_invariances(cuda):

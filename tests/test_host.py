@@ -101,7 +101,7 @@ def test_check_desc_and_error_mapping(lib):
         with pytest.raises((_lib.EnfError, NotImplementedError, AssertionError)):
             _lib.check(lib.enf_check_desc(ctypes.byref(bad)))
     # per-call options are validated too: unknown variant, masks requested without a buffer
-    for kw in (dict(variants=(3, 0)), dict(variants=(0, -1))):
+    for kw in (dict(variants=(4, 0)), dict(variants=(0, 3)), dict(variants=(0, -1))):
         assert lib.enf_check_desc(ctypes.byref(_lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1, **kw))) == -1
     nomask = _lib.make_desc(2, 100, 64, 2, 128, 16, 1, 2, 0, 1, 1)
     nomask.mask_mode = 2
@@ -115,6 +115,12 @@ def test_check_desc_and_error_mapping(lib):
     assert lib.enf_pair_scratch_bytes(ctypes.byref(small)) == 0 < lib.enf_pair_scratch_bytes(ctypes.byref(forced))
     assert lib.enf_workspace_bytes(ctypes.byref(forced)) > lib.enf_workspace_bytes(ctypes.byref(small))
     assert lib.enf_pair_variant(ctypes.byref(small), 0) == 1                      # ... and nothing sticks between calls
+    # 96 .. 191 workgroups of 128 queries and >= 128 latents: the z-fold kernel with the latents split over two workgroups
+    c3 = _lib.make_desc(4, 96 * 48, 128, 2, 128, 32, 3, 2, 1, 1, 1)
+    assert lib.enf_pair_variant(ctypes.byref(c3), 0) == 3
+    assert lib.enf_pair_variant(ctypes.byref(_lib.make_desc(4, 96 * 48, 64, 2, 128, 32, 3, 2, 1, 1, 1)), 0) == 1       # 64 latents: not split
+    c3ls = _lib.make_desc(4, 96 * 48, 128, 2, 128, 32, 3, 2, 1, 1, 1, variants=(1, 0))
+    assert lib.enf_workspace_bytes(ctypes.byref(c3)) > lib.enf_workspace_bytes(ctypes.byref(c3ls))
     # NULL buffers are rejected before anything touches the (absent) GPU
     assert lib.enf_forward(ctypes.byref(ok), None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
 
