@@ -19,6 +19,8 @@ int enf_launch_pair_bwd(const EnfDims&, const EnfLayout&, const char*, const flo
 int enf_launch_wz(const EnfDims&, const EnfLayout&, const char*, const float*, char*, float*, char*, char*, hipStream_t);
 int enf_launch_tail(const EnfDims&, const EnfLayout&, const char*, const float*, float*, const float*, float*, float*, float*,
                     int, int, hipStream_t);
+int enf_launch_tail_loss(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, float, float*, float*, float*,
+                         float*, hipStream_t);
 }
 
 size_t enf_xtd_part_bytes(const EnfDims& m, long long P);
@@ -273,6 +275,59 @@ extern "C" int enf_backward_latents_ex(const EnfDesc* d, const float* x, int64_t
                                 zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, nullptr, st))) return rc;
   if ((rc = enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st))) return rc;
   return ENF_OK;
+}
+
+
+// One inner step of the MAML loop in one call (SURVEY.md 8d's unit of work; pde_trainer.py:175-207): forward on the sampled points,
+// mean squared error against `target` and its gradient, backward to the latents.  Same kernels as enf_forward_stages +
+// enf_mse_value_grad + enf_backward_latents_ex with every REUSE flag, except that the tail runs ONCE (forward chain, loss and
+// backward chain in one kernel, enf_tail.hip: LOSS) and neither `out` nor `d out` exists.
+extern "C" int enf_fit_step(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a, const float* sigma,
+                            const void* packed, const float* target, float grad_scale, float* loss, float* dp, float* da,
+                            float* dsigma, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (!x || !p || !a || !packed || !target || !loss || !dp || !da || !dsigma || !workspace) return ENF_EINVAL;
+  if (d->use_window && !sigma) return ENF_EINVAL;
+  const EnfDims m = enf_dims(d);
+  const EnfLayout L = enf_layout(m);
+  const EnfWorkspace W = enf_workspace(m);
+  if (workspace_bytes < W.total) return ENF_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+  const char* blob = (const char*)packed;
+  const bool zf = enf_use_zfold(m), zb = enf_use_zfold_bwd(m);
+  if ((rc = side_join_pending(st, workspace))) return rc;
+  if ((rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
+  if ((rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), F(W.ybar), F(W.lse), zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
+                                zf ? ws + W.wzu : nullptr, enf_zfold_split(m) > 1 ? F(W.ysplit) : nullptr, 1, 1, st)))
+    return rc;
+  // what the backward pair kernel needs from the latent table alone runs on the side stream beside the tail
+  const size_t dlt_bytes = sizeof(float) * (size_t)m.B * m.Z * enf_lt_stride(m.H, m.D);
+  bool forked = false;
+  SideStream* side = zb ? side_stream() : nullptr;
+  if (side) {
+    std::lock_guard<std::mutex> lk(side->mu);
+    SidePending* e = side->entry(workspace);
+    if (e) {
+      if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) return ENF_ELAUNCH;
+      if ((rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, side->s))) return rc;
+      if (hipMemsetAsync(F(W.dlt), 0, dlt_bytes, side->s) != hipSuccess) return ENF_ELAUNCH;
+      if (hipEventRecord(e->join, side->s) != hipSuccess) return ENF_ELAUNCH;
+      e->pending = true;
+      forked = true;
+    }
+  }
+  if (!forked) {
+    if (zb && (rc = enf_launch_wz(m, L, blob, F(W.lt), nullptr, F(W.wzb), nullptr, ws + W.wzt, st))) return rc;
+    if (hipMemsetAsync(F(W.dlt), 0, dlt_bytes, st) != hipSuccess) return ENF_ELAUNCH;
+  }
+  if ((rc = enf_launch_tail_loss(m, L, blob, F(W.ybar), target, grad_scale, loss, F(W.dybar), F(W.delta), F(W.tail_act), st))) return rc;
+  if ((rc = side_join_pending(st, workspace))) return rc;
+  if ((rc = enf_launch_pair_bwd(m, L, blob, x, x_bstride, F(W.lt), F(W.lse), F(W.dybar), F(W.delta), F(W.dlt), nullptr,
+                                zb ? ws + W.wzt : nullptr, zb ? F(W.wzb) : nullptr, nullptr, st))) return rc;
+  return enf_launch_prologue_bwd(m, L, blob, p, sigma, F(W.an), F(W.kv), F(W.dlt), dp, da, dsigma, st);
 }
 
 extern "C" int enf_lt_layout(const EnfDesc* d, int* stride, int* off_u, int* off_v0, int* off_pose, int* off_wcoef, int* off_c) {

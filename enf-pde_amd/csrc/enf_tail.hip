@@ -20,6 +20,7 @@ struct TailArgs {
   float* out;            // forward: (B*N, O)
   const float* dout;     // backward
   float* dybar; float* delta; float* act;   // backward outputs + scratch (B*N x (2HD + 2D + 2))
+  const float* target; float* loss; float gscale, inv_n;     // fused loss (LOSS): d out = 2 (out - target) inv_n gscale, *loss += mean sq. error
   float* tdel;           // weight-gradient backward (WG): per query d a_B | d a_F1 | d a_O0 | d a_O2 (2HD + 2D floats); the layer INPUTS
                          // n^ | gelu(a_F1) | gelu(a_O0) | gelu(a_O2) replace the pre-activations in `act` (enf_train.hip forms X^T delta)
   int NQ, O;             // NQ = B*N queries
@@ -222,8 +223,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   }
 }
 
-template <int D, int H, bool BF16, bool LA2, bool RECOMP, bool WG = false>
+// LOSS (with RECOMP): the inner step's tail in ONE kernel -- forward chain, the reconstruction loss and its gradient
+// (pde_trainer.py:185: mean squared error over all B N O outputs; enf_loss.hip's arithmetic) formed in registers from the forward's
+// outputs, backward chain: no `out` / `d out` round trip and two launches less between the pair kernels of an inner step.
+template <int D, int H, bool BF16, bool LA2, bool RECOMP, bool WG = false, bool LOSS = false>
 __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
+  static_assert(!LOSS || RECOMP, "the fused loss needs the forward chain's outputs");
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
   using PG4 = Pan<1, NT, BF16>; using PG2 = Pan<KB, NT, BF16>; using PG0 = Pan<KB, NTH, BF16>; using PGH = Pan<KBH, NTH, BF16>;
@@ -242,12 +247,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
   Pipe P;
   P.rs = make_blob_rsrc(A.blob, (unsigned)A.L.total);
   P.rs2 = P.rs;
+  f32x4 o4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   if constexpr (RECOMP) {
     if constexpr (LA2) {
       __syncthreads();
       la2_first<PGH, PGH>(P, ring, (unsigned)A.L.atb, (unsigned)A.L.atf1, wave, lane);
     } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
-    f32x4 o4[2];
     // WG: the rows of `act` are rewritten in place below (layer inputs over pre-activations), so a clamped duplicate lane -- it shares
     // its row with the query's own lane in another wave -- must not store: its late pre-activation would land on the finished row
     tail_forward<D, H, BF16, true, LA2, PG4, PG2>(o4, yrow, act, A.L, cst, P, ring, (unsigned)A.L.gto4, (unsigned)A.L.gto2, lane, quad,
@@ -262,6 +267,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
 
   // ---- backward chain
   f32x4 g0[2];
+  if constexpr (LOSS) {
+    float se = 0.f;
+    const float gs = 2.0f * A.inv_n * A.gscale;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = 16 * t + 4 * quad + i;
+        const float dd = (o < A.O && qvalid) ? o4[t][i] - A.target[(size_t)qi * A.O + o] : 0.f;
+        se = fmaf(dd, dd, se);
+        g0[t][i] = dd * gs;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    if (lane == 0) atomicAdd(A.loss, se * A.inv_n);          // (one per wave, nobody waits for it; the caller zeroed *loss)
+  } else {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -269,6 +290,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
       const int o = 16 * t + 4 * quad + i;
       g0[t][i] = (o < A.O && qvalid) ? A.dout[(size_t)qi * A.O + o] : 0.f;
     }
+  }
   Frags<BF16, 1> F1;
   make_frags<BF16, 1>(F1, g0);
   f32x4 c[NT];
@@ -382,6 +404,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_bwd_kernel(TailArgs A) {
 template <int D, int H, bool BF16>
 static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
   const bool wg = bwd && A.tdel != nullptr;
+  const bool fused_loss = bwd && A.target != nullptr;
   using T = TailCfg<D, H, BF16>;
   dim3 grid((A.NQ + 16 * NWAVES - 1) / (16 * NWAVES));
   // few workgroups (at most one per CU): the deeper weight pipeline (LA2) instead of a second workgroup per CU
@@ -393,13 +416,17 @@ static int launch_tail(const TailArgs& A, bool bwd, bool opt, hipStream_t st) {
   const bool la2 = grid.x <= 256;
 #endif
   // opt: forward -> stash the pre-activations (SAVE); backward -> they are stashed, skip the recompute
-  static EnfAttrBits attr_done[3][2][2];     // [fwd / bwd / bwd + WG][la2][opt] (this function is one instantiation per D, H, BF16), one bit per device
+  static EnfAttrBits attr_done[4][2][2];     // [fwd / bwd / bwd + WG][la2][opt] (this function is one instantiation per D, H, BF16), one bit per device
   auto go = [&](void (*kern_ptr)(TailArgs)) -> int {
     const int smem = la2 ? T::SMEM3 : T::SMEM;
-    if (!enf_lds_attr(reinterpret_cast<const void*>(kern_ptr), smem, attr_done[wg ? 2 : bwd][la2][opt])) return ENF_ELAUNCH;
+    if (!enf_lds_attr(reinterpret_cast<const void*>(kern_ptr), smem, attr_done[fused_loss ? 3 : (wg ? 2 : bwd)][la2][opt])) return ENF_ELAUNCH;
     hipLaunchKernelGGL(kern_ptr, grid, dim3(NTHREADS), smem, st, A);
     return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
   };
+  if (fused_loss) {
+    if (wg || opt) return ENF_EINVAL;
+    return la2 ? go(enf_tail_bwd_kernel<D, H, BF16, true, true, false, true>) : go(enf_tail_bwd_kernel<D, H, BF16, false, true, false, true>);
+  }
   if (wg) {
     if (la2) return opt ? go(enf_tail_bwd_kernel<D, H, BF16, true, false, true>) : go(enf_tail_bwd_kernel<D, H, BF16, true, true, true>);
     return opt ? go(enf_tail_bwd_kernel<D, H, BF16, false, false, true>) : go(enf_tail_bwd_kernel<D, H, BF16, false, true, true>);
@@ -420,15 +447,38 @@ extern "C" int enf_launch_tail(const EnfDims& m, const EnfLayout& L, const char*
 }
 // tdel != NULL (backward only): the weight-gradient form of the backward -- it also leaves every layer's input (in `act`, in place
 // of the pre-activations) and delta (in `tdel`) for the X^T delta products of enf_train.hip
+extern "C" int enf_launch_tail_loss(const EnfDims& m, const EnfLayout& L, const char* blob, const float* ybar, const float* target,
+                                    float gscale, float* loss, float* dybar, float* delta, float* act, hipStream_t st);
 extern "C" int enf_launch_tail_wg(const EnfDims& m, const EnfLayout& L, const char* blob, const float* ybar, float* out,
                                   const float* dout, float* dybar, float* delta, float* act, float* tdel, int bwd, int opt, hipStream_t st) {
   if (m.OB != 1) return ENF_EUNSUPPORTED;
   TailArgs A;
+  A.target = nullptr; A.loss = nullptr; A.gscale = 0.f; A.inv_n = 0.f;
   A.tdel = tdel;
   A.ybar = ybar; A.blob = blob; A.L = L; A.out = out; A.dout = dout; A.dybar = dybar; A.delta = delta; A.act = act;
   A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.Ht * m.Dt);
 #define ENF_CASE(DD, HH)                                                                   \
   if (m.D == DD && m.H == HH) return m.bf16 ? launch_tail<DD, HH, true>(A, bwd != 0, opt != 0, st) : launch_tail<DD, HH, false>(A, bwd != 0, opt != 0, st);
+  ENF_CASE(128, 2)
+  ENF_CASE(64, 2)
+  ENF_CASE(128, 1)
+  ENF_CASE(64, 1)
+  ENF_CASE(64, 4)
+#undef ENF_CASE
+  return ENF_EUNSUPPORTED;
+}
+
+// the inner step's tail as one kernel: forward chain -> mean squared error against `target` (added to *loss) and its gradient ->
+// backward chain -> d ybar, delta
+extern "C" int enf_launch_tail_loss(const EnfDims& m, const EnfLayout& L, const char* blob, const float* ybar, const float* target,
+                                    float gscale, float* loss, float* dybar, float* delta, float* act, hipStream_t st) {
+  if (m.OB != 1) return ENF_EUNSUPPORTED;
+  TailArgs A;
+  A.ybar = ybar; A.blob = blob; A.L = L; A.out = nullptr; A.dout = nullptr; A.dybar = dybar; A.delta = delta; A.act = act; A.tdel = nullptr;
+  A.target = target; A.loss = loss; A.gscale = gscale; A.inv_n = 1.0f / ((float)m.B * (float)m.N * (float)m.O);
+  A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.Ht * m.Dt);
+#define ENF_CASE(DD, HH)                                                                   \
+  if (m.D == DD && m.H == HH) return m.bf16 ? launch_tail<DD, HH, true>(A, true, false, st) : launch_tail<DD, HH, false>(A, true, false, st);
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
   ENF_CASE(128, 1)

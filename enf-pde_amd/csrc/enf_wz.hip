@@ -33,6 +33,9 @@ struct WzArgs {
 };
 
 constexpr int WZ_WAVES = 4;
+#ifndef ENF_WZ_BWD_GRID
+#define ENF_WZ_BWD_GRID 128     // the backward's call (both orientations) runs beside the tail kernel of an inner step (64 workgroups)
+#endif
 #ifndef ENF_WZ_MAXGRID
 #define ENF_WZ_MAXGRID 256      // x 4 waves = one per SIMD (the bf16 128-wide instantiation holds 352 registers)
 #endif
@@ -210,7 +213,7 @@ static int launch_wz(const WzArgs& A, hipStream_t st) {
 #else
   constexpr int envgrid = 0;
 #endif
-  const int maxgrid = envgrid > 0 ? envgrid : (A.wzt ? ENF_WZ_MAXGRID / 2 : ENF_WZ_MAXGRID);
+  const int maxgrid = envgrid > 0 ? envgrid : (A.wzt ? ENF_WZ_BWD_GRID : ENF_WZ_MAXGRID);
   const int max_waves = maxgrid * WZ_WAVES;
   int lanes = A.BZ;
   while (lanes * COMBOS > max_waves && lanes > 1) lanes = (lanes + 1) / 2;

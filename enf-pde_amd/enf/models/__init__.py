@@ -19,7 +19,6 @@ from . import _pad
 
 __all__ = ["EquivariantCrossAttentionNeF", "TENSOR_PATHS", "tensor_paths"]
 
-_PREP = 0 if __import__("os").environ.get("ENF_PREPARE_BWD") == "0" else 32     # ENF_STAGE_PREPARE_BWD in the fused inner step (A/B switch)
 _BLK = "cross_attention_blocks_0"
 # ENF_W_* order of include/enf_hip.h -> path in the Flax parameter tree
 TENSOR_PATHS = [
@@ -75,6 +74,9 @@ def _set(tree, path, value):
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+FUSED_FIT_STEP = __import__("os").environ.get("ENF_FIT_STEP") != "0"      # mse_value_and_latent_grads through enf_fit_step (one call)
 
 
 class _EnfFunction(torch.autograd.Function):
@@ -463,24 +465,30 @@ class EquivariantCrossAttentionNeF:
         B, Z, N, dev = p_.shape[0], p_.shape[1], x.shape[1], p_.device
         desc = self._desc(B, N, Z, masks=self._masks)
         xb, xstride = self._x_arg(x)
-        HD = self._Hp * self._Dp
-        out = torch.empty((B, N, self.num_out), device=dev, dtype=torch.float32)
-        ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
-        lse = torch.empty((B, N, self._Hp), device=dev, dtype=torch.float32)
         ws = self._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.launch(dev, lib.enf_forward_stages, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
-                                          _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16 | _PREP, st)   # + TAIL_SAVE (+ PREPARE_BWD)
         tgt = target.float().contiguous()
-        if tgt.shape != out.shape:
-            raise AssertionError(f"target has shape {tuple(tgt.shape)}, expected {tuple(out.shape)}")
+        if tuple(tgt.shape) != (B, N, self.num_out):
+            raise AssertionError(f"target has shape {tuple(tgt.shape)}, expected {(B, N, self.num_out)}")
         loss = loss_out if loss_out is not None else torch.zeros(1, device=dev, dtype=torch.float32)
-        dout = torch.empty_like(out)
-        _lib.launch(dev, lib.enf_mse_value_grad, _ptr(out), _ptr(tgt), out.numel(), float(grad_scale), _ptr(dout), _ptr(loss), st)
         dp, da = torch.empty_like(p_), torch.empty_like(a_)
         dsig = torch.empty((B, Z, 1), device=dev, dtype=torch.float32)
-        _lib.launch(dev, lib.enf_backward_latents_ex, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_),
-                                               _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da),
-                                               _ptr(dsig), _ptr(ws), ws.numel(), 1 | 2 | (_PREP >> 3), st)   # latent table, tail stash (, side work) are the forward's
+        if not FUSED_FIT_STEP:       # the same step as three library calls (cross-check in the tests, A/B in scripts/)
+            HD = self._Hp * self._Dp
+            out = torch.empty((B, N, self.num_out), device=dev, dtype=torch.float32)
+            ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
+            lse = torch.empty((B, N, self._Hp), device=dev, dtype=torch.float32)
+            _lib.launch(dev, lib.enf_forward_stages, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
+                        _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), 15 | 16 | 32, st)       # + TAIL_SAVE + PREPARE_BWD
+            dout = torch.empty_like(out)
+            _lib.launch(dev, lib.enf_mse_value_grad, _ptr(out), _ptr(tgt), out.numel(), float(grad_scale), _ptr(dout), _ptr(loss), st)
+            _lib.launch(dev, lib.enf_backward_latents_ex, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_),
+                        _ptr(packed), _ptr(ybar), _ptr(lse), _ptr(dout), _ptr(dp), _ptr(da), _ptr(dsig), _ptr(ws), ws.numel(), 1 | 2 | 4, st)
+            self._ws_touch(ws)
+            return loss, dp, da, (dsig if sigma is not None else None)
+        # ONE library call per inner step (include/enf_hip.h: enf_fit_step): prologue, pair forward, the tail as a single kernel with
+        # the loss and its gradient formed in registers, pair backward, prologue backward
+        _lib.launch(dev, lib.enf_fit_step, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed), _ptr(tgt),
+                    float(grad_scale), _ptr(loss), _ptr(dp), _ptr(da), _ptr(dsig), _ptr(ws), ws.numel(), st)
         self._ws_touch(ws)
         return loss, dp, da, (dsig if sigma is not None else None)

@@ -259,6 +259,15 @@ int enf_pair_backward_ex(const EnfDesc* d, const float* x, int64_t x_bstride, co
  * them (same N, Z; B = mask_signals). */
 size_t enf_relu_mask_bytes(const EnfDesc* d);
 
+/* One inner step of the MAML loop (pde_trainer.py:175-207) in ONE call: forward on (x, p, a, sigma), *loss += mean((out - target)^2)
+ * (the caller zeroes *loss; target (B,N,O) fp32), and grad_scale * d loss / d(p, a, sigma) into dp / da / dsigma (OVERWRITTEN).
+ * Equals enf_forward + enf_mse_value_grad + enf_backward_latents on the same arguments; the per-query tail runs once, as a single
+ * kernel (forward chain, loss and its gradient in registers, backward chain), so neither `out` nor `d out` is materialised.
+ * `workspace`: enf_workspace_bytes(d), contents need not be kept. */
+int enf_fit_step(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a, const float* sigma,
+                 const void* packed, const float* target, float grad_scale, float* loss, float* dp, float* da, float* dsigma,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* Reconstruction loss of the inner loop and its gradient in one pass (pde_trainer.py:185):
  *   *loss += mean((out - target)^2)   (the caller zeroes *loss),   dout = 2 (out - target) / n * grad_scale  (dout may be NULL) */
 int enf_mse_value_grad(const float* out, const float* target, size_t n, float grad_scale, float* dout, float* loss,

@@ -178,3 +178,31 @@ def test_duplicate_waves_agree(cuda, D, H, precision):
             dup = sums[launched][:, 2:, :16 * 64 + H + 5]
             differ = (dup != ref).any(-1)
             assert not differ.any(), (it, int(differ.sum()), "duplicate waves differ from wave 1; per wave", differ.sum(0).tolist())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("invariant,N,Z,O", [("rel_pos_periodic", 300, 20, 1), ("ponita", 77, 5, 2), ("latitude_periodic", 130, 9, 3)])
+def test_fit_step_in_one_call_matches_the_three_calls_and_autograd(cuda, invariant, N, Z, O, precision, monkeypatch):
+    """enf_fit_step (one inner step: forward, mean squared error and its gradient inside the tail kernel, backward to the latents)
+    against the same step as enf_forward_stages + enf_mse_value_grad + enf_backward_latents_ex, and against autograd of
+    mean((nef.apply - target)^2) through the model API (pde_trainer.py:175-207)."""
+    from enf_pde_amd.enf import models as M
+    cfg = make_cfg(invariant, D=128 if invariant != "ponita" else 64, H=2, C=12, O=O, freq=(0.3, 0.6))
+    prm = R.init_params(17, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, 3, N, Z, 18)
+    y = np.random.default_rng(19).standard_normal((3, N, O))
+    nef = build_nef(cfg, precision)
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v, g=False: torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=g)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(M, "FUSED_FIT_STEP", fused)
+        res[fused] = nef.mse_value_and_latent_grads(params, t(x), t(p), t(a), t(s), t(y), grad_scale=3.0)
+    tp, ta, ts = t(p, True), t(a, True), t(s, True)
+    loss = ((nef.apply(params, t(x), tp, ta, ts) - t(y)) ** 2).mean()
+    (3.0 * loss).backward()
+    tol = 1e-5 if precision == "f32" else 2e-2
+    for other in (res[False], (loss.detach().reshape(1), tp.grad, ta.grad, ts.grad)):
+        assert abs(float(res[True][0]) - float(other[0])) < tol * float(other[0])
+        for g, r in zip(res[True][1:], other[1:]):
+            assert rel(g.cpu().numpy(), r.cpu().numpy()) < 10 * tol
