@@ -507,6 +507,48 @@ DEV void panel_gemm_flip(f32x4 (&acc)[TRANS ? MTOUT : 1], const Frags<BF16, KBIN
 }
 
 
+// ---- "A3": antiphase over a THREE-slot ring (single-stage panels).  The upper half of the workgroup's waves -- the SIMD-mates of
+// the lower half -- take each stage's barrier BEFORE its MFMAs, the lower half after them, so that on every SIMD one wave multiplies
+// while the other runs its vector epilogue.  Barrier b (the same instance for all waves) therefore completes when the late waves
+// have finished G_b and the early ones V_{b-1}: slot b % 3 is still being read by the early waves, panel b + 1 must be (and is:
+// issued behind barrier b - 1, waited for by every wave before it arrives) resident for the late waves' next G, and slot
+// (b + 2) % 3 -- last read for G_{b-1}, which every wave has behind it -- is free: panel b + 2 is issued into it behind the barrier.
+// Two slots cannot do this (the refill of a slot would race the early waves' reads of it); both halves meet every barrier once.
+template <int BYTES0, int BYTES1, int NW = NWAVES>
+DEV void first_stage_a3(Pipe& P, char* ring, unsigned panel0, unsigned panel1, int wave, int lane) {
+  P.cur = 0;
+  P.wave = __builtin_amdgcn_readfirstlane(wave);
+  P.early = P.wave >= NW / 2;
+  stage_issue_p<BYTES0, NW>(P, panel0, ring, lane);
+  stage_issue_p<BYTES1, NW>(P, panel1, ring + STAGE_MAX, lane);
+  stage_wait();
+  __syncthreads();
+}
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES, int INIT = INIT_ACC>
+DEV void panel_gemm_a3(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned next2, bool active, int lane,
+                       const float* bias = nullptr) {
+  using C = PanelCfg<KBIN, MTOUT, BF16>;
+  static_assert(C::SPP == 1, "A3 staging: single-stage panels");
+  char* refill = ring + ((P.cur + 2) % 3) * STAGE_MAX;
+  if (P.early) {
+    stage_wait();
+    __syncthreads();
+    if (next2 != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next2, refill, lane);
+  }
+  if (active) gemm_stage<BF16, KBIN, C::MTS, INIT>(acc, F, ring + P.cur * STAGE_MAX, lane, bias);
+  else if constexpr (INIT != INIT_ACC) {
+#pragma unroll
+    for (int mt = 0; mt < C::MTS; ++mt)
+      acc[mt] = INIT == INIT_BIAS ? *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (!P.early) {
+    stage_wait();
+    __syncthreads();
+    if (next2 != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next2, refill, lane);
+  }
+  P.cur = (P.cur + 1) % 3;
+}
+
 template <int BYTES, int NW = NWAVES, bool ANTI = false>
 DEV void first_stage(Pipe& P, char* ring, unsigned panel, int wave, int lane) {
   P.cur = 0;

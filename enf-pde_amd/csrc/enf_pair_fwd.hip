@@ -75,6 +75,9 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #ifndef ENF_ANTIPHASE
 #define ENF_ANTIPHASE false
 #endif
+#ifndef ENF_K2_A3             // z-fold bf16: antiphase staging over a three-slot ring (enf_device.h: panel_gemm_a3).  OFF: correct (189 forward /
+#define ENF_K2_A3 0           // golden tests) but 2 % SLOWER at the decode shape (1.153 vs 1.129 ms same-box, profiles/r03_ab_k2_a3.log): an MFMA
+#endif                        // holds the SIMD's vector issue for half its duration, so the mate's epilogue does not run "under" it for free
 #ifndef ENF_K2_LN_ASM         // the LayerNorm apply as scalar asm fmas (ln_apply, enf_device.h: the form K3 needed).  K2's fmaf loop packed
 #define ENF_K2_LN_ASM 1       // differently and never deviated (scripts/k3_race/fwd_probe.py); the asm form costs nothing (same-box A/B: decode
 #endif                        // 1.238-1.241 vs 1.240-1.250 ms), so K2 avoids the instruction class too
@@ -87,9 +90,9 @@ extern "C" int enf_debug_read_stamps(unsigned long long* dst) {
 #endif
 template <bool ZFOLD> struct PairWaves { static constexpr int NW = ZFOLD && ENF_ZFOLD_WAVES == 4 ? 4 : NWAVES; };
 
-template <int D, int H, bool BF16, int NW> struct PairSmem {
-  static constexpr int RING = 0;                                   // 2 slots
-  static constexpr int CONSTS = RING + 2 * STAGE_MAX;              // bq1 bv1 bf bm (D each) | bgb (2HD) | acq acv (2D each)
+template <int D, int H, bool BF16, int NW, int NSLOT = 2> struct PairSmem {
+  static constexpr int RING = 0;                                   // 2 slots (3: A3 staging)
+  static constexpr int CONSTS = RING + NSLOT * STAGE_MAX;              // bq1 bv1 bf bm (D each) | bgb (2HD) | acq acv (2D each)
   static constexpr int N_CONST = 4 * D + 2 * H * D + 4 * D;
   static constexpr int ZVEC = CONSTS + 4 * N_CONST;                // NWAVES x 2*H*D floats
   static constexpr int XCH = ZVEC + 4 * NW * 2 * H * D;            // NW x H x 3 x 16 floats
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   const int dx_ = INV >= 0 ? 2 : A.dx;
   using Cfg = PairCfg<D, BF16>;
   constexpr int NW = PairWaves<ZFOLD>::NW, NTH = 64 * NW;
-  using SM = PairSmem<D, H, BF16, NW>;
+  constexpr bool A3 = ZFOLD && BF16 && ENF_K2_A3 != 0 && NW == 8 && PairCfg<D, BF16>::DD::SPP == 1;
+  using SM = PairSmem<D, H, BF16, NW, A3 ? 3 : 2>;
   constexpr int KB = Cfg::KB, NT = Cfg::NT;
   constexpr int ST_DD = Cfg::DD::STAGE, ST_GB = Cfg::GB::STAGE, PANEL_GB = Cfg::GB::BYTES, PANEL_DD = Cfg::DD::BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,12 +152,18 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
   if constexpr (ZFOLD) P.rs2 = make_blob_rsrc(A.wz + (size_t)b * A.Z * H * PANEL_DD, (unsigned)(A.Z * H * PANEL_DD));
   else P.rs2 = P.rs;
-  first_stage<ST_DD, NW, ENF_ANTIPHASE>(P, ring, pQ1, wave, lane);
+  if constexpr (A3) first_stage_a3<ST_DD, ST_DD, NW>(P, ring, pQ1, pV1, wave, lane);
+  else first_stage<ST_DD, NW, ENF_ANTIPHASE>(P, ring, pQ1, wave, lane);
   // look-ahead staging: all five panels of a z-fold bf16 iteration are single 32 KB (8 KB) stages, so the stage after next is
   // issued behind each stage's closing barrier and streams under the vector epilogue that follows every stage of this kernel;
   // call sites pass `LA ? <stage after next> : <next stage>`
-  constexpr bool LA = ZFOLD && BF16 && ENF_K2_LA != 0 && !ENF_ANTIPHASE && Cfg::DD::SPP == 1;
-  if constexpr (LA) stage_issue_p<ST_DD, NW>(P, pV1, ring + STAGE_MAX, lane);
+  constexpr bool LA = A3 || (ZFOLD && BF16 && ENF_K2_LA != 0 && !ENF_ANTIPHASE && Cfg::DD::SPP == 1);   // (call sites name the stage AFTER next)
+  if constexpr (LA && !A3) stage_issue_p<ST_DD, NW>(P, pV1, ring + STAGE_MAX, lane);
+  // the z-fold stages of this kernel: 2-slot (optionally look-ahead) staging, or the antiphase 3-slot form
+  auto zgemm = [&](f32x4 (&acc_)[NT], const Frags<BF16, KB>& F_, unsigned panel_, unsigned next_, bool active_, const float* bias_) {
+    if constexpr (A3) panel_gemm_a3<KB, NT, BF16, ST_DD, NW, K2_INIT>(acc_, F_, P, ring, next_, active_, lane, bias_);
+    else panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc_, F_, P, ring, panel_, next_, active_, lane, bias_);
+  };
 
   // softmax state against a per-column reference logit (the first one seen); fp32 accumulators
   float sm_m[H], sm_l[H], sm_c[H];
@@ -210,7 +220,8 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       make_frags<BF16, KB>(F, acc);
       K2_BIAS(acc, c_bq1);
       STAMP(1);
-      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pQ1, LA ? pF : pV1, active, lane, c_bq1);
+      if constexpr (ZFOLD) zgemm(acc, F, pQ1, LA ? pF : pV1, active, c_bq1);
+      else panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pQ1, LA ? pF : pV1, active, lane, c_bq1);
       STAMP(2);
       const bool mread = K2_MASK_MODE == 2;                       // wave-uniform
       if (K2_MASK_MODE) {
@@ -253,7 +264,8 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       make_frags<BF16, KB>(F, acc);
       K2_BIAS(acc, c_bv1);
       STAMP(4);
-      panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pV1, LA ? STAGE_RS2 | (unsigned)(z * H * PANEL_DD) : pF, active, lane, c_bv1);
+      if constexpr (ZFOLD) zgemm(acc, F, pV1, LA ? STAGE_RS2 | (unsigned)(z * H * PANEL_DD) : pF, active, c_bv1);
+      else panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pV1, pF, active, lane, c_bv1);
       STAMP(5);
       const bool mread = K2_MASK_MODE == 2;
       if (K2_MASK_MODE) {
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       if constexpr (ZFOLD) {
         const unsigned wz0 = STAGE_RS2 | (unsigned)(z * H * PANEL_DD);
         const unsigned after = H > 1 ? wz0 + PANEL_DD : (it + 1 < iters ? pQ1 : NO_STAGE);
-        panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc, F, P, ring, pF, LA ? after : wz0, active, lane, c_bf);
+        zgemm(acc, F, pF, LA ? after : wz0, active, c_bf);
       }
       else panel_gemm<KB, NT, BF16, ST_GB, NW, K2_INIT>(acc, F, P, ring, pF, pGB, active, lane, c_bf);
       STAMP(7);
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
         const bool more = it + 1 < iters;
         const unsigned nx1 = h + 1 < H ? wzh + PANEL_DD : (more ? pQ1 : NO_STAGE);
         const unsigned nx2 = h + 2 < H ? wzh + 2 * PANEL_DD : (h + 2 == H ? (more ? pQ1 : NO_STAGE) : (more ? pV1 : NO_STAGE));
-        panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(v, F, P, ring, wzh, LA ? nx2 : nx1, active, lane, zv + H * D + h * D);
+        zgemm(v, F, wzh, LA ? nx2 : nx1, active, zv + H * D + h * D);
       } else {
         f32x4 dummy[1];
         gb_panel<D, BF16, ST_DD, false, NW>(v, dummy, F, P, ring, pGB + h * PANEL_GB, pM, active, c_bgb + 2 * h * D,
@@ -341,7 +353,8 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
     }
   }
 
-  pipe_finish(P);
+  if constexpr (!A3) pipe_finish(P);       // (A3: both halves have met every barrier)
+  else __syncthreads();                    // the ring is reused below
   if constexpr (ZFOLD) {
     if (A.zsplit > 1) {        // partial weighted sums against this workgroup's own reference logit + (m, l, c): merged afterwards
       if (n0 + col < A.N) {
@@ -457,7 +470,8 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
     if (A.mask_mode) return launch_pair_fwd<D, H, BF16, ZFOLD, true>(A, st);       // (the masked passes keep the run-time invariant)
   }
   constexpr int NW = PairWaves<ZFOLD>::NW;
-  using SM = PairSmem<D, H, BF16, NW>;
+  constexpr bool A3 = ZFOLD && BF16 && ENF_K2_A3 != 0 && NW == 8 && PairCfg<D, BF16>::DD::SPP == 1;
+  using SM = PairSmem<D, H, BF16, NW, A3 ? 3 : 2>;
   auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD, MASKS, INV>;
   static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
   if (!enf_lds_attr(reinterpret_cast<const void*>(kern), SM::TOTAL, attr_done)) return ENF_ELAUNCH;
