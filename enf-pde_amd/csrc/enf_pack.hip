@@ -495,8 +495,19 @@ __global__ __launch_bounds__(256) void enf_prologue_kernel(PrologueArgs A) {
   }
 }
 
+#ifndef ENF_PROLOGUE_MFMA     // bit 0: K1, bit 1: its backward, as matrix-pipe kernels over 16 latents per workgroup (enf_prologue.hip);
+#define ENF_PROLOGUE_MFMA 2   // clear: the kernels here.  Round 3, same box: K1 20.0 us here / 21.0 there, backward 32.0 here / 25.5 there
+#endif
+extern "C" int enf_launch_prologue_mfma(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, const float*, float*,
+                                        float*, float*, hipStream_t);
+extern "C" int enf_launch_prologue_bwd_mfma(const EnfDims&, const EnfLayout&, const char*, const float*, const float*, const float*,
+                                            const float*, const float*, float*, float*, float*, float*, hipStream_t);
+
 extern "C" int enf_launch_prologue(const EnfDims& m, const EnfLayout& L, const char* blob, const float* p, const float* a,
                                    const float* sigma, float* lt, float* an, float* kv, hipStream_t st) {
+#if ENF_PROLOGUE_MFMA & 1
+  if (m.D % 32 == 0) return enf_launch_prologue_mfma(m, L, blob, p, a, sigma, lt, an, kv, st);
+#endif
   PrologueArgs A;
   A.p = p; A.a = a; A.sigma = sigma; A.blob = blob; A.L = L; A.lt = lt; A.an = an; A.kv = kv;
   A.BZ = m.B * m.Z; A.H = m.H; A.D = m.D; A.C = m.C; A.dp = m.dp; A.inv = m.inv; A.Dt = m.Dt;
@@ -677,6 +688,9 @@ extern "C" int enf_launch_prologue_bwd(const EnfDims& m, const EnfLayout& L, con
 extern "C" int enf_launch_prologue_bwd_wg(const EnfDims& m, const EnfLayout& L, const char* blob, const float* p,
                                           const float* sigma, const float* an, const float* kv, const float* dlt, float* dp,
                                           float* da, float* dsigma, float* pg, hipStream_t st) {
+#if ENF_PROLOGUE_MFMA & 2
+  if (m.D % 32 == 0) return enf_launch_prologue_bwd_mfma(m, L, blob, p, sigma, an, kv, dlt, dp, da, dsigma, pg, st);
+#endif
   PrologueBwdArgs A;
   A.pg = pg;
   A.p = p; A.sigma = sigma; A.blob = blob; A.L = L; A.an = an; A.kv = kv; A.dlt = dlt;

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; FLAGS=$2; ONLY=$3
 mkdir -p variants build_variants/$NAME
 SRC=enf-pde_amd/csrc
-ALL="enf_api enf_pack enf_loss enf_wz enf_pair_fwd enf_pair_bwd enf_xtd enf_tail enf_train enf_debug enf_ode enf_ode_basis enf_ode_block"
+ALL="enf_api enf_pack enf_prologue enf_loss enf_wz enf_pair_fwd enf_pair_bwd enf_xtd enf_tail enf_train enf_debug enf_ode enf_ode_basis enf_ode_block"
 OBJS=""
 for f in $ALL; do
   if [ -z "$ONLY" ] || [[ " $ONLY " == *" $f "* ]] || [ ! -f $SRC/$f.o ]; then
