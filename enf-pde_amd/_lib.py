@@ -16,7 +16,7 @@ INVARIANT_IDS = {"rel_pos_periodic": 0, "latitude_periodic": 1, "polar_periodic"
 EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invariant_pose_dim", "enf_check_desc",
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
            "enf_backward_latents", "enf_backward_latents_ex", "enf_forward_stages", "enf_lt_layout", "enf_lt_layout_ext", "enf_pack_pair", "enf_pair_forward",
-           "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_pair_variant", "enf_backward_weights", "enf_backward_weights_scratch_bytes",
+           "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_pair_variant", "enf_pair_partition", "enf_backward_weights", "enf_backward_weights_scratch_bytes",
            "enf_backward_all", "enf_backward_all_scratch_bytes", "enf_fit_step",
            "enf_mse_value_grad",
            "enf_ode_conv_forward", "enf_ode_conv_backward_basis", "enf_ode_conv_backward_weight", "enf_ode_conv_backward_weight_scratch_bytes", "enf_ode_poly_num_features", "enf_ode_poly_forward",
@@ -146,6 +146,7 @@ def _bind(path, test_hooks):
     lib.enf_relu_mask_bytes.restype = sz
     lib.enf_relu_mask_bytes.argtypes = [dp]
     lib.enf_pair_variant.argtypes = [dp, ci]
+    lib.enf_pair_partition.argtypes = [dp] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.enf_backward_weights_scratch_bytes.restype = sz
     lib.enf_backward_weights_scratch_bytes.argtypes = [dp, ci]
     lib.enf_backward_weights.argtypes = [dp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp), vp, vp, sz, vp]

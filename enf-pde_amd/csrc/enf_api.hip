@@ -375,6 +375,17 @@ extern "C" int enf_pair_variant(const EnfDesc* d, int backward) {
   return sp > 1 ? ENF_VARIANT_ZFOLD_ZSPLIT : (sp == 1 ? ENF_VARIANT_ZFOLD : ENF_VARIANT_LATENT_SPLIT);
 }
 
+extern "C" int enf_pair_partition(const EnfDesc* d, int32_t* run, int32_t* workgroups, int32_t* parts) {
+  const int rc = enf_check_desc(d);
+  if (rc) return rc;
+  if (!run || !workgroups || !parts) return ENF_EINVAL;
+  const EnfDims m = enf_dims(d);
+  if (enf_zfold_split(m) < 2) return 0;
+  const EnfStreamK k = enf_zfold_streamk(m);
+  *run = k.len; *workgroups = k.wgs; *parts = k.parts;
+  return 1;
+}
+
 extern "C" size_t enf_pair_scratch_bytes(const EnfDesc* d) {
   if (enf_check_desc(d)) return 0;
   const EnfDims m = enf_dims(d);

@@ -197,32 +197,53 @@ ENF_HD inline int enf_lt_off_c(int H, int D) { return 2 * H * D + 8; }
 // EnfDesc.pair_fwd_variant forces the choice per call; ENF_VARIANT_AUTO is the heuristic below, a function of the shape
 // alone (only an -DENF_AB_SWITCHES build of the library lets ENF_ZFOLD=0 / 1 in the environment replace it).
 int enf_zfold_env(int backward);   // enf_api.hip: -1 (always, in the product library), 0 / 1
-// 0 = the latent-split kernel; s >= 1 = the z-fold kernel with every signal's latents split over s workgroups per 128-query tile
-// (s > 1 = ENF_VARIANT_ZFOLD_ZSPLIT: partial softmax sums, merged by enf_zsplit_merge_kernel).  AUTO splits when the 128-query
-// workgroups alone would under-fill the chip (< 192) and there are >= 128 latents: the split that minimises the number of
-// workgroup ROUNDS on 256 CUs per unit of work, rounds(wgs s) / s (+ 3 % per extra split for the per-workgroup prologue and the
-// merge), with >= 32 latents per workgroup and >= 192 workgroups in all -- 128 tiles -> 2 x (one round of 256), 144 tiles -> 3 x
-// (432 workgroups, two rounds of a third each: 0.67 of the unsplit time; 2 x would be 288 workgroups = two rounds of a half).
-constexpr int ENF_ZSPLIT_MAX = 4;
+// The z-fold kernel's work below 192 query tiles (ENF_VARIANT_ZFOLD_ZSPLIT), "stream-K" over the latents: the flattened
+// (signal, 128-query tile, latent) space -- tiles x Z latent steps -- is cut into <= 256 runs of `len` steps, one workgroup each, so a
+// single round of workgroups ends together whatever the tile count (144 tiles x 128 latents: 256 runs of 72 -- 0.56 of the unsplit time;
+// three equal parts per tile were 432 workgroups = two rounds of a third, 0.67).  A run that crosses a tile boundary is two segments of
+// one workgroup; every segment leaves partial softmax sums in its tile's slot (tile t is met by the runs floor(t Z / len) ..
+// floor(((t + 1) Z - 1) / len): `parts` = the most any tile has), merged by enf_zsplit_merge_kernel.
+struct EnfStreamK { int len, wgs, parts; };        // parts <= 1: not split
+inline EnfStreamK enf_streamk(long long tiles, int Z, int len_min) {
+  const long long total = tiles * Z;
+  long long len = (total + 255) / 256;
+  if (len < len_min) len = len_min;
+#ifdef ENF_SK_FORCE_LEN      // A/B builds only (scripts/build_variant.sh): e.g. 43 at config 3 = round 3's earlier three equal parts per tile
+  len = ENF_SK_FORCE_LEN;
+#endif
+  EnfStreamK k{(int)len, (int)((total + len - 1) / len), 1};
+  if (len >= Z) return k;
+  for (long long t = 0; t < tiles; ++t) {
+    const int n = (int)((t * Z + Z - 1) / len - (t * Z) / len) + 1;
+    if (n > k.parts) k.parts = n;
+  }
+  return k;
+}
+// AUTO splits when the 128-query tiles alone would under-fill the chip (< 192) and there are >= 128 latents, with >= 32 latent steps per
+// workgroup (its prologue, and the merge, are worth ~2 steps) and a run below 0.8 of Z (else the unsplit kernel or the latent-split one).
+inline EnfStreamK enf_zfold_streamk(const EnfDims& m) {
+  const EnfStreamK none{0, 0, 1};
+  const long long tiles = (long long)((m.N + 127) / 128) * m.B;
+  if (tiles * m.Z >= 0x7fffffffLL) return none;
+  if (m.var_fwd == ENF_VARIANT_ZFOLD_ZSPLIT) return m.Z >= 2 ? enf_streamk(tiles, m.Z, (m.Z + 2) / 3) : none;   // forced: <= 4 parts
+  if (m.var_fwd != ENF_VARIANT_AUTO || enf_zfold_env(0) >= 0) return none;
+  if (tiles >= 192 || m.Z < 128) return none;
+  const EnfStreamK k = enf_streamk(tiles, m.Z, 32);
+  return k.parts > 1 && k.len * 1.06 < 0.8 * m.Z ? k : none;
+}
+// 0 = the latent-split kernel; 1 = the z-fold kernel, one workgroup per 128-query tile walking all latents; s >= 2 = the z-fold kernel over
+// equal runs of latent steps, a tile's latents in up to s parts
 inline int enf_zfold_split(const EnfDims& m) {
   // one signal's folded matrices sit behind a buffer resource with 32-bit offsets: beyond 2 GB per signal (Z >= 32768
   // at D = 128, H = 2) only the latent-split variant can run
   if ((long long)m.Z * m.H * (long long)m.D * m.D * (m.bf16 ? 2 : 4) >= 0x7fffffffLL) return 0;
-  if (m.var_fwd == ENF_VARIANT_ZFOLD_ZSPLIT) return m.Z >= 2 ? 2 : 1;
+  const EnfStreamK k = enf_zfold_streamk(m);
+  if (k.parts > 1) return k.parts;
+  if (m.var_fwd == ENF_VARIANT_ZFOLD_ZSPLIT) return 1;
   if (m.var_fwd != ENF_VARIANT_AUTO) return m.var_fwd == ENF_VARIANT_ZFOLD ? 1 : 0;
   const int mode = enf_zfold_env(0);
   if (mode >= 0) return mode;
-  const long long wgs = (long long)((m.N + 127) / 128) * m.B;
-  if (wgs >= 192) return 1;
-  if (m.Z < 128) return 0;
-  int best = 0;
-  double best_cost = 0.8;            // below this fraction of the unsplit z-fold time the split pays against the latent-split kernel
-  for (int s = 2; s <= ENF_ZSPLIT_MAX; ++s) {
-    if (m.Z / s < 32 || wgs * s < 192) continue;
-    const double cost = (double)((wgs * s + 255) / 256) / s * (1.0 + 0.03 * (s - 1));
-    if (cost < best_cost) { best_cost = cost; best = s; }
-  }
-  return best;
+  return (long long)((m.N + 127) / 128) * m.B >= 192 ? 1 : 0;
 }
 inline bool enf_use_zfold(const EnfDims& m) { return enf_zfold_split(m) > 0; }
 

@@ -32,7 +32,9 @@ struct PairFwdArgs {
   int xcd_remap;                          // z-fold: 1 when B % 8 == 0 (see the kernel)
   unsigned* masks; int mask_mode, mask_B; // relu masks (ENF_MASK_*): buffer, 0 off / 1 write / 2 read, signals per mask set
   int B, N, Z, dx, inv, use_window, qg;   // qg: query groups per workgroup (1,2,4,8); ZS = 8/qg
-  int zsplit;                             // z-fold: workgroups per query tile (grid.z), each walks Z / zsplit latents (ENF_VARIANT_ZFOLD_ZSPLIT)
+  int zsplit;                             // z-fold, ENF_VARIANT_ZFOLD_ZSPLIT: the most parts a query tile's latents are cut into (1: no split)
+  int sk_len;                             // zsplit > 1: latent steps per workgroup -- workgroup c walks steps [c sk_len, (c + 1) sk_len) of the
+                                          // flattened (signal, query tile, latent) space (enf_layout.h: enf_zfold_streamk)
   float* ysplit;                          // zsplit > 1: [zsplit][B N HD] partial sums | [zsplit][B N H][3] (m, l, c), merged by enf_zsplit_merge_kernel
 };
 
@@ -135,8 +137,13 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
     by = xcd + 8 * (slot / (int)gridDim.x);
     bx = slot % (int)gridDim.x;
   }
-  const int b = by, n0 = (bx * QG + qgi) * 16;
-  const int n = min(n0 + col, A.N - 1);
+  // ENF_VARIANT_ZFOLD_ZSPLIT ("stream-K" over the latents): this workgroup owns the latent steps [f0, f1) of the flattened
+  // (signal, query tile, latent) space -- the same count for every workgroup, so one round of <= 256 workgroups ends together -- and
+  // walks them as one or more SEGMENTS, each a run of latents of one query tile that leaves partial sums in that tile's slot `part`
+  const bool split = ZFOLD && A.zsplit > 1;
+  const int tiles_n = (A.N + 16 * QG - 1) / (16 * QG);
+  int f0 = split ? (int)blockIdx.x * A.sk_len : 0;
+  const int f1 = split ? min(f0 + A.sk_len, tiles_n * A.B * A.Z) : 0;
   const char* blob = A.blob;
   auto G = [&](size_t off) { return reinterpret_cast<const float*>(blob + off); };
 
@@ -145,11 +152,27 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   for (int i = tid; i < 2 * H * D; i += NTH) c_bgb[i] = G(A.L.bgb)[i];
   for (int i = tid; i < 2 * D; i += NTH) { c_acq[i] = G(A.L.acq)[i]; c_acv[i] = G(A.L.acv)[i]; }
 
-  const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * dx_, dx_, inv_id);
   const unsigned pQ1 = (unsigned)A.L.aq1, pV1 = (unsigned)A.L.av1, pF = (unsigned)A.L.af, pGB = (unsigned)A.L.agb, pM = (unsigned)A.L.am;
-
   Pipe P;
   P.rs = make_blob_rsrc(blob, (unsigned)A.L.total);
+  float sm_m[H], sm_l[H], sm_c[H];     // softmax state against a per-column reference logit (the first one seen); fp32 accumulators
+  f32x4 Y[H][NT];
+  int b, n0;
+ for (;;) {                            // one pass per segment (exactly one without the split)
+  int z_lo = 0, seg_iters = 0, part = 0;
+  if (split) {
+    const int tf = f0 / A.Z;
+    z_lo = f0 - tf * A.Z;
+    seg_iters = min(A.Z - z_lo, f1 - f0);
+    part = (int)blockIdx.x - (tf * A.Z) / A.sk_len;
+    by = tf / tiles_n;
+    bx = tf - by * tiles_n;
+    f0 += seg_iters;
+  }
+  b = by;
+  n0 = (bx * QG + qgi) * 16;
+  const int n = min(n0 + col, A.N - 1);
+  const QueryPt q = load_query(A.x + (size_t)b * A.x_bstride + (size_t)n * dx_, dx_, inv_id);
   if constexpr (ZFOLD) P.rs2 = make_blob_rsrc(A.wz + (size_t)b * A.Z * H * PANEL_DD, (unsigned)(A.Z * H * PANEL_DD));
   else P.rs2 = P.rs;
   if constexpr (A3) first_stage_a3<ST_DD, ST_DD, NW>(P, ring, pQ1, pV1, wave, lane);
@@ -165,9 +188,6 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
     else panel_gemm<KB, NT, BF16, ST_DD, NW, K2_INIT, LA>(acc_, F_, P, ring, panel_, next_, active_, lane, bias_);
   };
 
-  // softmax state against a per-column reference logit (the first one seen); fp32 accumulators
-  float sm_m[H], sm_l[H], sm_c[H];
-  f32x4 Y[H][NT];
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     sm_m[h] = -INFINITY; sm_l[h] = 0.f; sm_c[h] = 0.f;
@@ -176,10 +196,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   }
 
   const int ltstride = enf_lt_stride(H, D);
-  // z-fold with zsplit > 1: this workgroup walks the latents [z_lo, z_lo + iters) of its signal and leaves PARTIAL sums
-  const int zchunk = ZFOLD ? (A.Z + A.zsplit - 1) / A.zsplit : 0;
-  const int z_lo = ZFOLD ? (int)blockIdx.z * zchunk : 0;
-  const int iters = ZFOLD ? max(0, min(A.Z, z_lo + zchunk) - z_lo) : (A.Z + ZS - 1) / ZS;
+  const int iters = split ? seg_iters : ZFOLD ? A.Z : (A.Z + ZS - 1) / ZS;
   for (int it = 0; it < iters; ++it) {
     const int z = ZFOLD ? z_lo + it : it * ZS + zs;
     const bool active = z < A.Z;
@@ -356,21 +373,24 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
   if constexpr (!A3) pipe_finish(P);       // (A3: both halves have met every barrier)
   else __syncthreads();                    // the ring is reused below
   if constexpr (ZFOLD) {
-    if (A.zsplit > 1) {        // partial weighted sums against this workgroup's own reference logit + (m, l, c): merged afterwards
+    if (split) {               // partial weighted sums against this segment's own reference logit + (m, l, c): merged afterwards
       if (n0 + col < A.N) {
         const size_t BN = (size_t)A.B * A.N, row = (size_t)b * A.N + n0 + col;
-        float* yo = A.ysplit + ((size_t)blockIdx.z * BN + row) * (H * D);
-        float* so = A.ysplit + (size_t)A.zsplit * BN * (H * D) + ((size_t)blockIdx.z * BN + row) * (H * 3);
+        float* yo = A.ysplit + ((size_t)part * BN + row) * (H * D);
+        float* so = A.ysplit + (size_t)A.zsplit * BN * (H * D) + ((size_t)part * BN + row) * (H * 3);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(yo + h * D + 16 * t + 4 * quad) = Y[h][t];
-          if (quad == 0) { so[h * 3] = iters > 0 ? sm_m[h] : -INFINITY; so[h * 3 + 1] = sm_l[h]; so[h * 3 + 2] = sm_c[h]; }
+          if (quad == 0) { so[h * 3] = sm_m[h]; so[h * 3 + 1] = sm_l[h]; so[h * 3 + 2] = sm_c[h]; }
         }
       }
-      return;
+      if (f0 >= f1) return;
+      continue;                // (the closing barrier of the last stage is behind every wave: the ring and zv are free again)
     }
   }
+  break;
+ }
   // ---- combine the ZS latent splits of each query group (all staging is finished: ring is free)
   if (quad == 0) {
 #pragma unroll
@@ -443,19 +463,22 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
 // ENF_VARIANT_ZFOLD_ZSPLIT: ybar[row][h][:] = sum_s e^{m_s - m*} Y_s / L - C / L,  lse = m* + log L  with  L = sum_s e^{m_s - m*} l_s (C alike):
 // exactly the in-kernel combine of the latent-split variant, across workgroups.  One thread per (row, feature).
 __global__ __launch_bounds__(256) void enf_zsplit_merge_kernel(const float* __restrict__ ysplit, int S, long long BN, int H, int D,
-                                                              float* __restrict__ ybar, float* __restrict__ lse) {
+                                                              int N, int Z, int sk_len, float* __restrict__ ybar, float* __restrict__ lse) {
   const int HD = H * D;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= BN * HD) return;
   const long long row = e / HD;
   const int c = (int)(e % HD), h = c / D;
+  // the parts of this row's query tile: the workgroups whose runs meet its latent steps [tf Z, (tf + 1) Z)
+  const int tiles_n = (N + 127) / 128, tf = (int)(row / N) * tiles_n + (int)(row % N) / 128;
+  const int parts = (tf * Z + Z - 1) / sk_len - (tf * Z) / sk_len + 1;
   const float* st = ysplit + (size_t)S * BN * HD;
   float ms = -INFINITY;
-  for (int s = 0; s < S; ++s) ms = fmaxf(ms, st[((size_t)s * BN + row) * (H * 3) + h * 3]);
+  for (int s = 0; s < parts; ++s) ms = fmaxf(ms, st[((size_t)s * BN + row) * (H * 3) + h * 3]);
   float L = 0.f, C = 0.f, y = 0.f;
-  for (int s = 0; s < S; ++s) {
+  for (int s = 0; s < parts; ++s) {
     const float* q = st + ((size_t)s * BN + row) * (H * 3) + h * 3;
-    const float aw = __expf(q[0] - ms);          // exp(-inf) = 0: a split that saw no latent
+    const float aw = __expf(q[0] - ms);
     L = fmaf(aw, q[1], L);
     C = fmaf(aw, q[2], C);
     y = fmaf(aw, ysplit[((size_t)s * BN + row) * HD + c], y);
@@ -475,12 +498,13 @@ static int launch_pair_fwd(const PairFwdArgs& A, hipStream_t st) {
   auto kern = enf_pair_fwd_kernel<D, H, BF16, ZFOLD, MASKS, INV>;
   static EnfAttrBits attr_done{0};          // one per instantiation, one bit per device
   if (!enf_lds_attr(reinterpret_cast<const void*>(kern), SM::TOTAL, attr_done)) return ENF_ELAUNCH;
-  dim3 grid((A.N + 16 * A.qg - 1) / (16 * A.qg), A.B, ZFOLD ? A.zsplit : 1);
+  dim3 grid((A.N + 16 * A.qg - 1) / (16 * A.qg), A.B);
+  if (ZFOLD && A.zsplit > 1) grid = dim3((unsigned)(((long long)grid.x * A.B * A.Z + A.sk_len - 1) / A.sk_len));
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), SM::TOTAL, st, A);
   if (ZFOLD && A.zsplit > 1) {
     const long long BN = (long long)A.B * A.N, tot = BN * H * D;
     hipLaunchKernelGGL(enf_zsplit_merge_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)A.ysplit, A.zsplit, BN, H, D,
-                       A.ybar, A.lse);
+                       A.N, A.Z, A.sk_len, A.ybar, A.lse);
   }
   return hipGetLastError() == hipSuccess ? 0 : ENF_ELAUNCH;
 }
@@ -502,9 +526,11 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;
   A.qg = NWAVES / zs;
   const bool zfold = wz && wzb && wzu && (size_t)m.Z * m.H * enf_panel_bytes(m.D, m.D, m.bf16) < 0x7fffffffu;
-  A.zsplit = zfold && ysplit && enf_zfold_split(m) > 1 ? enf_zfold_split(m) : 1;
+  const EnfStreamK sk = enf_zfold_streamk(m);
+  A.zsplit = zfold && ysplit && sk.parts > 1 ? sk.parts : 1;
+  A.sk_len = A.zsplit > 1 ? sk.len : 0;
   A.ysplit = ysplit;
-  A.xcd_remap = zfold && m.B % 8 == 0;        // (grid.z slabs keep the residue: gridDim.x * B is a multiple of 8 then)
+  A.xcd_remap = zfold && m.B % 8 == 0 && A.zsplit == 1;
   if (zfold) {
     A.qg = PairWaves<true>::NW;
     if (run_fold) {

@@ -60,10 +60,11 @@ enum {
   ENF_VARIANT_AUTO = 0,          /* by problem size */
   ENF_VARIANT_LATENT_SPLIT = 1,  /* forward: the 8 waves split Z; backward: one wave = one latent */
   ENF_VARIANT_ZFOLD = 2,         /* forward: >= 192 workgroups of 128 queries; backward: >= 192 latents */
-  ENF_VARIANT_ZFOLD_ZSPLIT = 3   /* forward only: the z-fold kernel with every signal's latents split over 2-4 workgroups per 128 queries
-                                    (partial softmax sums merged by a small kernel; forced: 2): AUTO picks the split that fills 256 CUs
-                                    in the fewest rounds when fewer than 192 such workgroups exist and Z >= 128 -- e.g. 128 latents
-                                    on a 96 x 48 sphere grid, 4 signals: 144 workgroups -> 3 x 144 */
+  ENF_VARIANT_ZFOLD_ZSPLIT = 3   /* forward only: the z-fold kernel over equal runs of latent steps -- the (signal, 128-query tile, latent) space
+                                    cut into <= 256 runs, one workgroup each, a tile's partial softmax sums merged by a small kernel
+                                    (enf_pair_partition).  AUTO picks it when fewer than 192 tiles exist and Z >= 128 -- e.g. 128 latents on
+                                    a 96 x 48 sphere grid, 4 signals: 144 tiles -> 256 runs of 72.  In this variant the last bits of a
+                                    query's value depend on the call's shape (the run boundaries order the partial sums) */
 };
 
 /* relu masks of a call (see "Relu masks" below) */
@@ -393,6 +394,11 @@ int enf_backward_weights(const EnfDesc* d, const float* x, int64_t x_bstride, co
  * ENF_VARIANT_ZFOLD (or, forward only, ENF_VARIANT_ZFOLD_ZSPLIT); `backward` = 0 for the forward kernel, 1 for the backward kernel.
  * Negative ENF_E* on a bad descriptor. */
 int enf_pair_variant(const EnfDesc* d, int backward);
+/* How ENF_VARIANT_ZFOLD_ZSPLIT cuts the forward pair kernel's work: the flattened (signal, 128-query tile, latent) space of
+ * tiles x Z latent steps is walked by `workgroups` workgroups of `run` consecutive steps each (the last one may be shorter); a query
+ * tile's latents are met by at most `parts` of them (the partial-sum slots the workspace holds).  Returns 1 and fills the three values when
+ * the descriptor resolves to that variant, 0 (values untouched) when it does not, negative ENF_E* on a bad descriptor. */
+int enf_pair_partition(const EnfDesc* d, int32_t* run, int32_t* workgroups, int32_t* parts);
 
 #ifdef __cplusplus
 }

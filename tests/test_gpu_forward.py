@@ -152,10 +152,11 @@ def test_forward_config3_sphere(cuda, invariant, precision):
     assert err < TOL[precision] and mse < 1e-5
 
 
-def test_latent_table_is_reused_only_for_the_same_latents(cuda):
+def test_latent_table_is_reused_only_for_the_same_latents(cuda, pair_variant):
     """A forward on the same latent tensors and weights as the last call on the workspace (a decode right after the fit's
     final-loss forward) skips the prologue kernel; any change of the latents -- another tensor, or the same one modified in
-    place -- or of the weights must not."""
+    place -- or of the weights must not.  (A query's value does not depend on how many other queries the call carries, bit for bit --
+    except in the split z-fold variant, whose runs of latent steps, and with them the order of a tile's partial sums, follow from the shape.)"""
     import ctypes
     from enf_pde_amd import _lib
     cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
@@ -185,7 +186,8 @@ def test_latent_table_is_reused_only_for_the_same_latents(cuda):
             assert [c & 1 for c in calls] == [0, 0]           # both found the table of the first call
             fresh = build_nef(cfg, "f32")
             ref = fresh.apply(fresh.load_params(prm, device=cuda), xl, tp, ta, ts)
-            assert torch.equal(full, ref) and torch.equal(small, ref[:, :40])
+            assert torch.equal(full, ref)
+            assert torch.equal(small, ref[:, :40]) if pair_variant != "z_fold_zsplit" else torch.allclose(small, ref[:, :40], rtol=0, atol=2e-6)
             calls.clear()
             ta.add_(0.05)                                     # same tensor, new contents
             moved = nef.apply(params, xl, tp, ta, ts)

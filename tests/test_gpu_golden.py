@@ -70,7 +70,7 @@ def test_inner_loop_matches_golden_trace(cuda, precision):
             assert _rel(v.cpu().numpy() - init, ref - init) < tol * 20, k
 
 
-def test_full_size_properties(cuda):
+def test_full_size_properties(cuda, pair_variant):
     """BASELINE config 2 at full size (B=2, N=64^2, Z=64): properties that need no oracle run."""
     cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
     prm = R.init_params(3, cfg, jitter=0.1)
@@ -98,7 +98,10 @@ def test_full_size_properties(cuda):
     # (3) query-chunked decode == one call (pde_trainer.py:397-402), materialised x == broadcast x
     from enf_pde_amd.fitting import decode
     o4 = decode(nef, params, t(coords), t(p), t(a), t(s), chunk=512)
-    assert torch.equal(o4, base)
+    if pair_variant == "z_fold_zsplit":       # its runs of latent steps -- the order of a tile's partial sums -- follow from the call's shape
+        assert (o4 - base).abs().max().item() < 2e-6 * scale
+    else:
+        assert torch.equal(o4, base)
     o5 = nef.apply(params, x.contiguous(), t(p), t(a), t(s))
     assert torch.equal(o5, base)
     # (4) determinism

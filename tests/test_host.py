@@ -115,7 +115,7 @@ def test_check_desc_and_error_mapping(lib):
     assert lib.enf_pair_scratch_bytes(ctypes.byref(small)) == 0 < lib.enf_pair_scratch_bytes(ctypes.byref(forced))
     assert lib.enf_workspace_bytes(ctypes.byref(forced)) > lib.enf_workspace_bytes(ctypes.byref(small))
     assert lib.enf_pair_variant(ctypes.byref(small), 0) == 1                      # ... and nothing sticks between calls
-    # 96 .. 191 workgroups of 128 queries and >= 128 latents: the z-fold kernel with the latents split over two workgroups
+    # fewer than 192 tiles of 128 queries and >= 128 latents: the z-fold kernel over equal runs of latent steps
     c3 = _lib.make_desc(4, 96 * 48, 128, 2, 128, 32, 3, 2, 1, 1, 1)
     assert lib.enf_pair_variant(ctypes.byref(c3), 0) == 3
     assert lib.enf_pair_variant(ctypes.byref(_lib.make_desc(4, 96 * 48, 64, 2, 128, 32, 3, 2, 1, 1, 1)), 0) == 1       # 64 latents: not split
@@ -123,6 +123,60 @@ def test_check_desc_and_error_mapping(lib):
     assert lib.enf_workspace_bytes(ctypes.byref(c3)) > lib.enf_workspace_bytes(ctypes.byref(c3ls))
     # NULL buffers are rejected before anything touches the (absent) GPU
     assert lib.enf_forward(ctypes.byref(ok), None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
+
+
+def _partition(desc):
+    from enf_pde_amd import _lib
+    lib = _lib.load()
+    v = [ctypes.c_int32(-1) for _ in range(3)]
+    rc = lib.enf_pair_partition(ctypes.byref(desc), *[ctypes.byref(x) for x in v])
+    return rc, tuple(x.value for x in v)
+
+
+@pytest.mark.parametrize("B,N,Z,forced", [(4, 96 * 48, 128, False), (8, 2048, 128, False), (1, 4096, 512, False), (2, 100, 64, True),
+                                          (3, 300, 7, True), (1, 16, 2, True), (5, 1000, 33, True), (2, 128 * 70, 200, False)])
+def test_split_z_fold_partition_covers_every_latent_step_once(B, N, Z, forced):
+    """enf_pair_partition: the runs the split z-fold kernel's workgroups walk, replayed with the kernel's own arithmetic (enf_pair_fwd.hip:
+    segment loop; enf_zsplit_merge_kernel: parts of a tile), cover every (signal, tile, latent) exactly once, every segment lands in a slot
+    below `parts`, no two segments of a tile share a slot, and the merge reads exactly the slots that were written."""
+    from enf_pde_amd import _lib
+    d = _lib.make_desc(B, N, Z, 2, 128, 16, 1, 2, 0, 1, 1, variants=(3 if forced else 0, 0))
+    rc, (run, wgs, parts) = _partition(d)
+    assert rc == 1 and _lib.load().enf_pair_variant(ctypes.byref(d), 0) == 3
+    tiles = (N + 127) // 128 * B
+    total = tiles * Z
+    assert wgs == -(-total // run) and (forced or (wgs <= 256 and run >= 32))
+    seen = np.zeros((tiles, Z), dtype=np.int32)
+    slots = [set() for _ in range(tiles)]
+    for c in range(wgs):
+        f0, f1 = c * run, min((c + 1) * run, total)
+        assert f0 < f1
+        while f0 < f1:
+            tf, z_lo = divmod(f0, Z)
+            it = min(Z - z_lo, f1 - f0)
+            part = c - (tf * Z) // run
+            assert 0 <= part < parts and part not in slots[tf]
+            slots[tf].add(part)
+            seen[tf, z_lo:z_lo + it] += 1
+            f0 += it
+    assert (seen == 1).all()
+    for tf in range(tiles):
+        n = (tf * Z + Z - 1) // run - (tf * Z) // run + 1
+        assert slots[tf] == set(range(n))
+    assert max(len(x) for x in slots) == parts
+    # the workspace holds `parts` partial-sum slots
+    ls = _lib.make_desc(B, N, Z, 2, 128, 16, 1, 2, 0, 1, 1, variants=(2, 0))
+    extra = _lib.load().enf_pair_scratch_bytes(ctypes.byref(d)) - _lib.load().enf_pair_scratch_bytes(ctypes.byref(ls))
+    assert extra == 4 * parts * (B * N * 256 + B * N * 2 * 3)
+
+
+def test_partition_is_reported_only_for_the_split_variant():
+    from enf_pde_amd import _lib
+    for kw in (dict(), dict(variants=(1, 0)), dict(variants=(2, 0))):
+        rc, vals = _partition(_lib.make_desc(16, 4096, 64, 2, 128, 16, 1, 2, 0, 1, 1, **kw))
+        assert rc == 0 and vals == (-1, -1, -1)
+    # config 3's decode: 144 tiles x 128 latents in 256 runs of 72, a tile in at most 3 parts
+    assert _partition(_lib.make_desc(4, 96 * 48, 128, 2, 128, 32, 3, 2, 1, 1, 1)) == (1, (72, 256, 3))
 
 
 def test_invariant_factory_mirrors_reference():
