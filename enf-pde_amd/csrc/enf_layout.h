@@ -221,14 +221,20 @@ inline EnfStreamK enf_streamk(long long tiles, int Z, int len_min) {
 }
 // AUTO splits when the 128-query tiles alone would under-fill the chip (< 192) and there are >= 128 latents, with >= 32 latent steps per
 // workgroup (its prologue, and the merge, are worth ~2 steps) and a run below 0.8 of Z (else the unsplit kernel or the latent-split one).
+#ifndef ENF_SK_MIN_Z
+#define ENF_SK_MIN_Z 128
+#endif
+#ifndef ENF_SK_MIN_RUN
+#define ENF_SK_MIN_RUN 32
+#endif
 inline EnfStreamK enf_zfold_streamk(const EnfDims& m) {
   const EnfStreamK none{0, 0, 1};
   const long long tiles = (long long)((m.N + 127) / 128) * m.B;
   if (tiles * m.Z >= 0x7fffffffLL) return none;
   if (m.var_fwd == ENF_VARIANT_ZFOLD_ZSPLIT) return m.Z >= 2 ? enf_streamk(tiles, m.Z, (m.Z + 2) / 3) : none;   // forced: <= 4 parts
   if (m.var_fwd != ENF_VARIANT_AUTO || enf_zfold_env(0) >= 0) return none;
-  if (tiles >= 192 || m.Z < 128) return none;
-  const EnfStreamK k = enf_streamk(tiles, m.Z, 32);
+  if (tiles >= 192 || m.Z < ENF_SK_MIN_Z) return none;
+  const EnfStreamK k = enf_streamk(tiles, m.Z, ENF_SK_MIN_RUN);
   return k.parts > 1 && k.len * 1.06 < 0.8 * m.Z ? k : none;
 }
 // 0 = the latent-split kernel; 1 = the z-fold kernel, one workgroup per 128-query tile walking all latents; s >= 2 = the z-fold kernel over
