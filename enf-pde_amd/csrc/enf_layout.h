@@ -220,7 +220,7 @@ inline EnfStreamK enf_streamk(long long tiles, int Z, int len_min) {
   return k;
 }
 // AUTO splits when the 128-query tiles alone would under-fill the chip (< 192) and there are >= 128 latents, with >= 32 latent steps per
-// workgroup (its prologue, and the merge, are worth ~2 steps) and a run below 0.8 of Z (else the unsplit kernel or the latent-split one).
+// workgroup, when that beats the latent-split kernel by the estimate below.
 #ifndef ENF_SK_MIN_Z
 #define ENF_SK_MIN_Z 128
 #endif
@@ -235,7 +235,12 @@ inline EnfStreamK enf_zfold_streamk(const EnfDims& m) {
   if (m.var_fwd != ENF_VARIANT_AUTO || enf_zfold_env(0) >= 0) return none;
   if (tiles >= 192 || m.Z < ENF_SK_MIN_Z) return none;
   const EnfStreamK k = enf_streamk(tiles, m.Z, ENF_SK_MIN_RUN);
-  return k.parts > 1 && k.len * 1.06 < 0.8 * m.Z ? k : none;
+  // against the latent-split kernel: a run costs its latent steps + ~5 (fold kernel, merge), and in the time of one latent step (128
+  // pairs on each of 256 CUs at best) the latent-split kernel gets through ~22,000 pairs (measured at D = 128, H = 2: 9.1 us against
+  // 0.41 ns per pair).  Config 3 (144 tiles x 128 latents): 77 against 107 -> split; config 4's fit shape (32 tiles x 128 latents: 128
+  // runs of 32 would fill half the chip): 37 against 24 -> latent-split, 0.21 against 0.29 ms measured.
+  const double latent_split_steps = (double)m.B * m.N * m.Z / 22000.0;
+  return k.parts > 1 && k.len + 5 < 0.9 * latent_split_steps ? k : none;
 }
 // 0 = the latent-split kernel; 1 = the z-fold kernel, one workgroup per 128-query tile walking all latents; s >= 2 = the z-fold kernel over
 // equal runs of latent steps, a tile's latents in up to s parts

@@ -177,6 +177,9 @@ def test_partition_is_reported_only_for_the_split_variant():
         assert rc == 0 and vals == (-1, -1, -1)
     # config 3's decode: 144 tiles x 128 latents in 256 runs of 72, a tile in at most 3 parts
     assert _partition(_lib.make_desc(4, 96 * 48, 128, 2, 128, 32, 3, 2, 1, 1, 1)) == (1, (72, 256, 3))
+    # config 4's fit shape (8 signals x 512 points x 128 latents): 128 runs of 32 would fill half the chip -- the latent-split kernel
+    c4 = _lib.make_desc(8, 512, 128, 2, 128, 16, 1, 2, 0, 1, 1)
+    assert _partition(c4)[0] == 0 and _lib.load().enf_pair_variant(ctypes.byref(c4), 0) == 1
 
 
 def test_invariant_factory_mirrors_reference():
