@@ -6,10 +6,10 @@ R=$PWD
 cd /tmp && export TMPDIR=/tmp
 for cfg in 2 4 3; do
 for v in pro0 pro3; do
-  rm -rf $R/$O/c17_$v
-  ENF_HIP_LIB=$R/variants/libenf_$v.so timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/c17_$v -o p -- python3 $R/bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-meta --no-ode --events-steps 0 --no-accuracy > /dev/null 2>&1
+  rm -rf $R/$O/prologue_$v
+  ENF_HIP_LIB=$R/variants/libenf_$v.so timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prologue_$v -o p -- python3 $R/bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-meta --no-ode --events-steps 0 --no-accuracy > /dev/null 2>&1
   echo "cfg $cfg $v"
-  python3 - $R/$O/c17_$v <<'PY'
+  python3 - $R/$O/prologue_$v <<'PY'
 import csv,sys,glob
 f=glob.glob(sys.argv[1]+'/**/*kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
