@@ -294,6 +294,11 @@ template <int NT, bool FAST = false> DEV void gelu_tiles(f32x4 (&X)[NT]) {
 #endif
   }
 }
+DEV f32x2 lo2(const f32x4& x) { return __builtin_shufflevector(x, x, 0, 1); }
+DEV f32x2 hi2(const f32x4& x) { return __builtin_shufflevector(x, x, 2, 3); }
+#ifndef ENF_GELU_DG_FMA
+#define ENF_GELU_DG_FMA 1
+#endif
 // gelu and its derivative from ONE exp + rcp (the backward kernel needs both for the same pre-activation):
 // X <- gelu(X), G <- gelu'(X), two values per instruction where the ISA has a packed form
 DEV void gelu_fg2(f32x2 x, f32x2& g, f32x2& dg) {
@@ -309,7 +314,11 @@ DEV void gelu_fg2(f32x2 x, f32x2& g, f32x2& dg) {
   s[0] = __builtin_amdgcn_rcpf(e[0]);
   s[1] = __builtin_amdgcn_rcpf(e[1]);
   g = x * s;
+#if ENF_GELU_DG_FMA
+  dg = (g - g * s) * (x2 * (6.0f * c * 0.044715f) + 2.0f * c) + s;       // (g - g s: ONE packed fma; 1 - s would be two scalar subtractions)
+#else
   dg = g * (1.0f - s) * (x2 * (6.0f * c * 0.044715f) + 2.0f * c) + s;
+#endif
 }
 // the same one value at a time (no register-pair constraints for the allocator: the packed form spills in K3)
 DEV void gelu_fg1(float x, float& g, float& dg) {
@@ -320,6 +329,14 @@ DEV void gelu_fg1(float x, float& g, float& dg) {
   const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
   g = x * s;
   dg = fmaf(g - g * s, fmaf(x2, 6.0f * c * 0.044715f, 2.0f * c), s);
+}
+// one tile: g <- gelu(x), x <- gelu'(x); the polynomial parts two values per instruction, the two transcendentals per value
+DEV void gelu_fg_tile(f32x4& x, f32x4& g) {
+  f32x2 g0, d0, g1, d1;
+  gelu_fg2(lo2(x), g0, d0);
+  gelu_fg2(hi2(x), g1, d1);
+  g = f32x4{g0[0], g0[1], g1[0], g1[1]};
+  x = f32x4{d0[0], d0[1], d1[0], d1[1]};
 }
 // in place: X <- gelu(X), returns gelu'(X) in G
 template <int NT> DEV void gelu_fg_tiles(f32x4 (&X)[NT], f32x4 (&G)[NT]) {
@@ -559,14 +576,58 @@ DEV void first_stage(Pipe& P, char* ring, unsigned panel, int wave, int lane) {
   if (!P.early) { stage_wait(); __syncthreads(); }
 }
 
-// LayerNorm statistics over the NT*16 features of this lane's column: biased variance, eps 1e-6,
-// one pass (E[x^2] - E[x]^2, flax.linen.LayerNorm's default use_fast_variance=True)
-template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd, float inv_n = 1.0f / (16 * NT)) {
-  float s = 0.f, q = 0.f;
+// Per-lane sums over a lane's NT x 4 values, two at a time: even / odd running sums in one register pair each, so a sum costs one
+// v_pk_add_f32 / v_pk_fma_f32 per TWO elements (plain operands: no op_sel, no neg).  Written with a single accumulator the additions are a
+// serial chain the compiler may not reassociate: 64 vector instructions per LayerNorm instead of 34 -- 6 % of K3's, 8 % of K2's.
+#ifndef ENF_PK_SUMS
+#define ENF_PK_SUMS 1
+#endif
+// s = sum x, q = sum x^2
+template <int NT> DEV void tiles_sum_sq(const f32x4 (&X)[NT], float& s, float& q) {
+#if ENF_PK_SUMS
+  f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x2 a = lo2(X[t]), b = hi2(X[t]);
+    s2 += a; q2 = __builtin_elementwise_fma(a, a, q2);
+    s2 += b; q2 = __builtin_elementwise_fma(b, b, q2);
+  }
+  s = s2[0] + s2[1]; q = q2[0] + q2[1];
+#else
+  s = 0.f; q = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += X[t][i]; q = fmaf(X[t][i], X[t][i], q); }
+#endif
+}
+// s = sum a, d = sum a b      (`get(t)` yields tile t of b: a register array or parked fragments)
+template <int NT, typename GetB> DEV void tiles_sum_dot(const f32x4 (&A)[NT], GetB get, float& s, float& d) {
+#if ENF_PK_SUMS
+  f32x2 s2 = {0.f, 0.f}, d2 = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 bt = get(t);
+    s2 += lo2(A[t]); d2 = __builtin_elementwise_fma(lo2(A[t]), lo2(bt), d2);
+    s2 += hi2(A[t]); d2 = __builtin_elementwise_fma(hi2(A[t]), hi2(bt), d2);
+  }
+  s = s2[0] + s2[1]; d = d2[0] + d2[1];
+#else
+  s = 0.f; d = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 bt = get(t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s += A[t][i]; d = fmaf(A[t][i], bt[i], d); }
+  }
+#endif
+}
+
+// LayerNorm statistics over the NT*16 features of this lane's column: biased variance, eps 1e-6,
+// one pass (E[x^2] - E[x]^2, flax.linen.LayerNorm's default use_fast_variance=True)
+template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd, float inv_n = 1.0f / (16 * NT)) {
+  float s, q;
+  tiles_sum_sq<NT>(X, s, q);
   mu = xquad_sum(s) * inv_n;          // inv_n = 1 / (number of real features): zero padding adds nothing to the sums
   const float ex2 = xquad_sum(q) * inv_n;
   rstd = rsqrtf(fmaxf(ex2 - mu * mu, 0.f) + 1e-6f);

@@ -90,6 +90,12 @@
 #ifndef ENF_K3_DN_LATE        // z-fold: the d n^ GEMMs run after both heads (their inputs parked as fragments) instead of inside them
 #define ENF_K3_DN_LATE 1
 #endif
+#ifndef ENF_K3_GELU_PK        // the fused gelu / gelu' with its polynomial parts as packed instructions (gelu_fg_tile)
+#define ENF_K3_GELU_PK 1
+#endif
+#ifndef ENF_K3_DOT_PK         // the four-term dot products of the flipped d v0 sums as packed multiplies
+#define ENF_K3_DOT_PK 1
+#endif
 #ifndef ENF_K3_ZF_EARLY_DY    // z-fold heads: d ybar / delta requested before the head's first GEMM stage
 #define ENF_K3_ZF_EARLY_DY 1
 #endif
@@ -635,6 +641,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           if (STORE && A.masks) {
             acc[t][i] = (maskv >> (4 * t + i)) & 1u ? acc[t][i] : 0.f;
           } else {
+            // relu as an integer maximum (relu_f), the mask bit from its bits: min(bits, 1) is 1 exactly where a2 > 0 -- three
+            // instructions per element where compare + select + or + a NaN-quieting fmaxf were five
             if (acc[t][i] > 0.f) relu_mask |= 1u << (4 * t + i);
             acc[t][i] = fmaxf(acc[t][i], 0.f);
           }
@@ -650,6 +658,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       K3_SCHED_FENCE();
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+#if ENF_K3_GELU_PK
+        gelu_fg_tile(a3[t], nh[t]);
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float g, d;
@@ -657,6 +668,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           nh[t][i] = g;
           a3[t][i] = d;
         }
+#endif
         asm volatile("" : "+v"(nh[t]), "+v"(a3[t]));
         K3_SCHED_FENCE();
       }
@@ -715,6 +727,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         // one exp + rcp per element, a5 <- gelu'(a5) in place (the same 32 registers it was kept alive in anyway)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+#if ENF_K3_GELU_PK
+          gelu_fg_tile(a5[t], v[t]);
+#else
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float g, d;
@@ -722,6 +737,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
             v[t][i] = g;
             a5[t][i] = d;
           }
+#endif
           asm volatile("" : "+v"(v[t]), "+v"(a5[t]));
           K3_SCHED_FENCE();
         }
@@ -744,10 +760,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t);
         }
 #endif
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { s0 = fmaf(dy[t][i], v[t][i], s0); sd += dy[t][i]; }
+        tiles_sum_dot<NT>(dy, [&](int t) { return v[t]; }, sd, s0);
         const float datt = xquad_sum(s0);
         dlogit[h] = nvalid ? att[h] * (datt - delta_h) : 0.f;
         const float ah = nvalid ? att[h] : 0.f;
@@ -785,7 +798,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
               none, F, P, ring, pWG + h * PANEL_DD, LA ? nxt2 : nxt, lane,
               [&](int mt) { const float bc = c_bgb[h * D + 16 * mt + col]; return f32x4{bc, bc, bc, bc}; },
               [&](int mt, const f32x4& af) {
+#if ENF_K3_DOT_PK
+                const f32x2 p2 = __builtin_elementwise_fma(hi2(af), hi2(dvf[mt]), lo2(af) * lo2(dvf[mt]));
+                part[mt] = p2[0] + p2[1];
+#else
                 part[mt] = af[0] * dvf[mt][0] + af[1] * dvf[mt][1] + af[2] * dvf[mt][2] + af[3] * dvf[mt][3];
+#endif
               });
 #if ENF_K3_LDSACC
           lacc_flush((H + h) * NT, part);
@@ -880,11 +898,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int t = 0; t < NT; ++t) dy[t] = *reinterpret_cast<const f32x4*>(dyrow + 16 * t + 4 * quad);
       }
 #endif
-      float s0 = 0.f, sd = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s0 = fmaf(dy[t][i], v[t][i], s0); sd += dy[t][i]; }
+      float s0, sd;
+      tiles_sum_dot<NT>(dy, [&](int t) { return v[t]; }, sd, s0);
       const float datt = xquad_sum(s0);
       dlogit[h] = nvalid ? att[h] * (datt - K3_DELTA(h)) : 0.f;
       const float ah = nvalid ? att[h] : 0.f;
@@ -970,17 +985,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
     float dinv[4] = {0.f, 0.f, 0.f, 0.f};
     float dlat[2] = {0.f, 0.f};           // ball / ball_lat: gradient rows 4, 5 of the gc panels (quad-1 lanes)
     {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      float s1, s2;
 #if ENF_K3_PARK
-        const f32x4 nht = Parked<BF16, NT>{F}.get(t);
+      tiles_sum_dot<NT>(dnh, [&](int t) { return Parked<BF16, NT>{F}.get(t); }, s1, s2);
 #else
-        const f32x4 nht = nh[t];
+      tiles_sum_dot<NT>(dnh, [&](int t) { return nh[t]; }, s1, s2);
 #endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s1 += dnh[t][i]; s2 = fmaf(dnh[t][i], nht[i], s2); }
-      }
       const float m1 = xquad_sum(s1) * A.inv_d, m2 = xquad_sum(s2) * A.inv_d;
       const float m1r = m1 * r1, nm2r = -m2 * r1;
 #pragma unroll
@@ -1004,7 +1014,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = ((relu_mask >> (4 * t + i)) & 1u) ? acc[t][i] : 0.f;             // d a2
+        for (int i = 0; i < 4; ++i)       // d a2
+          acc[t][i] = ((relu_mask >> (4 * t + i)) & 1u) ? acc[t][i] : 0.f;
       make_frags<BF16, KB>(F, acc);
       if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA2], srow, D, F, quad);
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(acc, F, P, ring, gV1, LA ? gQ1 : pQ1, true, lane);      // d E_v

@@ -187,7 +187,7 @@ def test_latent_table_is_reused_only_for_the_same_latents(cuda, pair_variant):
             fresh = build_nef(cfg, "f32")
             ref = fresh.apply(fresh.load_params(prm, device=cuda), xl, tp, ta, ts)
             assert torch.equal(full, ref)
-            assert torch.equal(small, ref[:, :40]) if pair_variant != "z_fold_zsplit" else torch.allclose(small, ref[:, :40], rtol=0, atol=2e-6)
+            assert torch.equal(small, ref[:, :40]) if pair_variant != "z_fold_zsplit" else torch.allclose(small, ref[:, :40], rtol=0, atol=5e-6)
             calls.clear()
             ta.add_(0.05)                                     # same tensor, new contents
             moved = nef.apply(params, xl, tp, ta, ts)

@@ -99,7 +99,7 @@ def test_full_size_properties(cuda, pair_variant):
     from enf_pde_amd.fitting import decode
     o4 = decode(nef, params, t(coords), t(p), t(a), t(s), chunk=512)
     if pair_variant == "z_fold_zsplit":       # its runs of latent steps -- the order of a tile's partial sums -- follow from the call's shape
-        assert (o4 - base).abs().max().item() < 2e-6 * scale
+        assert (o4 - base).abs().max().item() < 5e-6 * scale
     else:
         assert torch.equal(o4, base)
     o5 = nef.apply(params, x.contiguous(), t(p), t(a), t(s))
