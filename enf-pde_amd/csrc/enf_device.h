@@ -36,13 +36,31 @@ struct Frags {
   T f[BF16 ? KB : 2 * KB];
 };
 
+// two floats -> one word of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Written element by element
+// (`f[j] = (__bf16)x`) hipcc keeps the packed conversion only where nothing touches the halves afterwards; in front of relu_frags'
+// 16-bit integer maximum it converted every value alone (the second operand a zero) and merged the halves with v_perm_b32: three
+// instructions per pair (K2's z loop: 64 of 1,150 vector instructions)
+#ifndef ENF_CVT_PK2
+#define ENF_CVT_PK2 1
+#endif
+typedef float f32x2_cvt __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_cvt __attribute__((ext_vector_type(2)));
+DEV unsigned bf16_pack2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cvt{a, b}, bf16x2_cvt));
+}
 template <bool BF16, int KB>
 DEV void make_frags(Frags<BF16, KB>& F, const f32x4 (&X)[2 * KB]) {
 #pragma unroll
   for (int blk = 0; blk < KB; ++blk) {
     if constexpr (BF16) {
+#if ENF_CVT_PK2
+      const u32x4 w = {bf16_pack2(X[2 * blk][0], X[2 * blk][1]), bf16_pack2(X[2 * blk][2], X[2 * blk][3]),
+                       bf16_pack2(X[2 * blk + 1][0], X[2 * blk + 1][1]), bf16_pack2(X[2 * blk + 1][2], X[2 * blk + 1][3])};
+      F.f[blk] = __builtin_bit_cast(bf16x8, w);
+#else
 #pragma unroll
       for (int j = 0; j < 8; ++j) F.f[blk][j] = (__bf16)X[2 * blk + (j >> 2)][j & 3];
+#endif
     } else {
       F.f[2 * blk] = X[2 * blk];
       F.f[2 * blk + 1] = X[2 * blk + 1];

@@ -1,9 +1,9 @@
 #!/bin/bash
-# packed per-lane sums (ENF_PK_SUMS=1, default) against the single-accumulator sums (variant base = the previous commit): parity subset, then the headline bench
+# the working tree (default) against the previous commit (variant base, built from a worktree of HEAD): parity subset, then the headline bench
 # with its per-kernel legs, interleaved on one box
 O=gpurun_out/r03
 mkdir -p $O
-timeout -k 10 1000 python -m pytest tests/test_gpu_forward.py tests/test_gpu_backward.py tests/test_gpu_golden.py tests/test_gpu_reentrancy.py tests/test_gpu_weight_grads.py tests/test_gpu_bf16_contract.py -m gpu -x -q > $O/pk_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 $O/pk_tests.log
+timeout -k 10 1000 python -m pytest tests/test_gpu_forward.py tests/test_gpu_backward.py tests/test_gpu_golden.py tests/test_gpu_reentrancy.py tests/test_gpu_weight_grads.py tests/test_gpu_bf16_contract.py tests/test_gpu_layers.py tests/test_gpu_narrow.py tests/test_gpu_ball.py -m gpu -x -q > $O/pk_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 $O/pk_tests.log
 [ $rc = 0 ] || exit 1
 for v in base default base default base default; do
   L=variants/libenf_$v.so; [ $v = default ] && L=
