@@ -641,6 +641,29 @@ template <int NT, typename GetB> DEV void tiles_sum_dot(const f32x4 (&A)[NT], Ge
 #endif
 }
 
+// d = sum a b
+template <int NT, typename GetA, typename GetB> DEV float tiles_dot(GetA geta, GetB getb) {
+#if ENF_PK_SUMS
+  f32x2 d2 = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 at = geta(t), bt = getb(t);
+    d2 = __builtin_elementwise_fma(lo2(at), lo2(bt), d2);
+    d2 = __builtin_elementwise_fma(hi2(at), hi2(bt), d2);
+  }
+  return d2[0] + d2[1];
+#else
+  float d = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 at = geta(t), bt = getb(t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d = fmaf(at[i], bt[i], d);
+  }
+  return d;
+#endif
+}
+
 // LayerNorm statistics over the NT*16 features of this lane's column: biased variance, eps 1e-6,
 // one pass (E[x^2] - E[x]^2, flax.linen.LayerNorm's default use_fast_variance=True)
 template <int NT> DEV void ln_stats(const f32x4 (&X)[NT], float& mu, float& rstd, float inv_n = 1.0f / (16 * NT)) {

@@ -604,13 +604,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       const bool masked = STORE && A.masks != nullptr;
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const f32x4 u = rowvec(zv + h * D, t, quad);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) s = fmaf(masked ? acc[t][i] : fmaxf(acc[t][i], 0.f), u[i], s);
-        }
+        const float s = tiles_dot<NT>(
+            [&](int t) { return masked ? acc[t] : f32x4{relu_f(acc[t][0]), relu_f(acc[t][1]), relu_f(acc[t][2]), relu_f(acc[t][3])}; },
+            [&](int t) { return rowvec(zv + h * D, t, quad); });
         const float lg = xquad_sum(s) + cz[h] + win;
         att[h] = __expf(lg - K3_LSE(h));
       }
@@ -1064,7 +1060,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
               r2 = (mflip[2] >> (4 * mt)) & 1u ? af[2] : 0.f; r3 = (mflip[3] >> (4 * mt)) & 1u ? af[3] : 0.f;
             } else { r0 = relu_f(af[0]); r1 = relu_f(af[1]); r2 = relu_f(af[2]); r3 = relu_f(af[3]); }
 #pragma unroll
-            for (int h = 0; h < H; ++h) upart[h][mt] = dl[h][0] * r0 + dl[h][1] * r1 + dl[h][2] * r2 + dl[h][3] * r3;
+            for (int h = 0; h < H; ++h) {
+#if ENF_K3_DOT_PK
+              const f32x2 p2 = __builtin_elementwise_fma(f32x2{r2, r3}, f32x2{dl[h][2], dl[h][3]}, f32x2{r0, r1} * f32x2{dl[h][0], dl[h][1]});
+              upart[h][mt] = p2[0] + p2[1];
+#else
+              upart[h][mt] = dl[h][0] * r0 + dl[h][1] * r1 + dl[h][2] * r2 + dl[h][3] * r3;
+#endif
+            }
           }, c_bq1);                                                                                             // a1
 #pragma unroll
       for (int h = 0; h < H; ++h) {

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       } else
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        float s = 0.f;
+        float s = 0.f;           // (as a packed-pair sum -- tiles_dot, enf_device.h -- this loop measured 0.6 % SLOWER on the fit-shape forward)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const f32x4 u = rowvec(zv + h * D, t, quad);
