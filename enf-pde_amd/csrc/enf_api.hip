@@ -170,12 +170,15 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
   float* yb = ybar ? ybar : F(W.ybar);
   const bool zf = enf_use_zfold(m);
   float* ls = lse ? lse : F(W.lse);
+  // ENF_STAGE_YBAR_HALF: the hand-off to the tail as bf16 (the launchers' flag bit 1)
+  const bool yhalf = (stages & ENF_STAGE_YBAR_HALF) && m.bf16 && !ybar && (stages & ENF_STAGE_PAIR) && (stages & ENF_STAGE_TAIL) &&
+                     !(stages & ENF_STAGE_TAIL_SAVE) && enf_zfold_split(m) <= 1;
   if ((rc = side_join_pending(st, workspace))) return rc;
   if ((stages & ENF_STAGE_PROLOGUE) && (rc = enf_launch_prologue(m, L, blob, p, a, sigma, F(W.lt), F(W.an), F(W.kv), st))) return rc;
   if ((stages & (ENF_STAGE_PAIR | ENF_STAGE_FOLD)) &&
       (rc = enf_launch_pair_fwd(m, L, blob, x, x_bstride, F(W.lt), yb, ls, zf ? ws + W.wz : nullptr, zf ? F(W.wzb) : nullptr,
                                 zf ? ws + W.wzu : nullptr, enf_zfold_split(m) > 1 ? F(W.ysplit) : nullptr, (stages & ENF_STAGE_FOLD) != 0,
-                                (stages & ENF_STAGE_PAIR) != 0, st)))
+                                ((stages & ENF_STAGE_PAIR) != 0 ? 1 : 0) | (yhalf ? 2 : 0), st)))
     return rc;
   if ((stages & ENF_STAGE_PREPARE_BWD) && enf_use_zfold_bwd(m)) {
     // what the backward needs from the latent table alone -- its per-latent folded matrices, the zeroed gradient table --
@@ -195,7 +198,7 @@ extern "C" int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bs
   }
   const bool tsave = (stages & ENF_STAGE_TAIL_SAVE) != 0;      // stash the tail's pre-activations for the backward that follows
   if ((stages & ENF_STAGE_TAIL) &&
-      (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, tsave ? F(W.tail_act) : nullptr, 0, tsave ? 1 : 0, st)))
+      (rc = enf_launch_tail(m, L, blob, yb, out, nullptr, nullptr, nullptr, tsave ? F(W.tail_act) : nullptr, 0, (tsave ? 1 : 0) | (yhalf ? 2 : 0), st)))
     return rc;
   return ENF_OK;
 }

@@ -35,6 +35,7 @@ struct PairFwdArgs {
   int zsplit;                             // z-fold, ENF_VARIANT_ZFOLD_ZSPLIT: the most parts a query tile's latents are cut into (1: no split)
   int sk_len;                             // zsplit > 1: latent steps per workgroup -- workgroup c walks steps [c sk_len, (c + 1) sk_len) of the
                                           // flattened (signal, query tile, latent) space (enf_layout.h: enf_zfold_streamk)
+  int ybar_half;                          // ENF_STAGE_YBAR_HALF: `ybar` is written as bf16 rows (H D x 2 bytes) for the tail kernel of the same call
   float* ysplit;                          // zsplit > 1: [zsplit][B N HD] partial sums | [zsplit][B N H][3] (m, l, c), merged by enf_zsplit_merge_kernel
 };
 
@@ -453,7 +454,12 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       for (int t = 0; t < NT; ++t) {
         f32x4 o = Y[h][t];
         o[0] -= cs; o[1] -= cs; o[2] -= cs; o[3] -= cs;
-        *reinterpret_cast<f32x4*>(yo + h * D + 16 * t + 4 * quad) = o;
+        if (A.ybar_half) {      // (wave-uniform) round to nearest even, as the tail's make_frags would
+          unsigned short* yh = reinterpret_cast<unsigned short*>(A.ybar) + ((size_t)b * A.N + n0 + col) * (H * D);
+          *reinterpret_cast<uint2*>(yh + h * D + 16 * t + 4 * quad) = uint2{bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3])};
+        } else {
+          *reinterpret_cast<f32x4*>(yo + h * D + 16 * t + 4 * quad) = o;
+        }
       }
       if (quad == 0) A.lse[((size_t)b * A.N + n0 + col) * H + h] = mstar[h] + __logf(Ltot[h]);
     }
@@ -520,7 +526,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   PairFwdArgs A;
   A.x = x; A.x_bstride = x_bstride; A.lt = lt; A.blob = blob; A.L = L; A.ybar = ybar; A.lse = lse; A.wz = wz; A.wzb = wzb; A.wzu = wzu; A.inv_d = 1.0f / (float)m.Dt;
   A.B = m.B; A.N = m.N; A.Z = m.Z; A.dx = m.dx; A.inv = m.inv; A.use_window = m.use_window;
-  A.masks = m.masks; A.mask_mode = run_pair ? m.mask_mode : 0; A.mask_B = m.mask_B;
+  A.masks = m.masks; A.mask_mode = (run_pair & 1) ? m.mask_mode : 0; A.mask_B = m.mask_B;
   // as many latent splits as there are latents to split (up to 8); the rest of the 8 waves take more queries
   int zs = 1;
   while (zs < NWAVES && zs * 2 <= m.Z) zs *= 2;
@@ -530,6 +536,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
   A.zsplit = zfold && ysplit && sk.parts > 1 ? sk.parts : 1;
   A.sk_len = A.zsplit > 1 ? sk.len : 0;
   A.ysplit = ysplit;
+  A.ybar_half = (run_pair & 2) && A.zsplit == 1 && m.bf16;
   A.xcd_remap = zfold && m.B % 8 == 0 && A.zsplit == 1;
   if (zfold) {
     A.qg = PairWaves<true>::NW;
@@ -538,7 +545,7 @@ extern "C" int enf_launch_pair_fwd(const EnfDims& m, const EnfLayout& L, const c
       if (rc) return rc;
     }
   }
-  if (!run_pair) return 0;
+  if (!(run_pair & 1)) return 0;
 #define ENF_CASE(DD, HH)                                                                                      \
   if (m.D == DD && m.H == HH) {                                                                               \
     if (zfold) return m.bf16 ? launch_pair_fwd<DD, HH, true, true>(A, st) : launch_pair_fwd<DD, HH, false, true>(A, st); \

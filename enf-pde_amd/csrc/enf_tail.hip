@@ -23,6 +23,7 @@ struct TailArgs {
   const float* target; float* loss; float gscale, inv_n;     // fused loss (LOSS): d out = 2 (out - target) inv_n gscale, *loss += mean sq. error
   float* tdel;           // weight-gradient backward (WG): per query d a_B | d a_F1 | d a_O0 | d a_O2 (2HD + 2D floats); the layer INPUTS
                          // n^ | gelu(a_F1) | gelu(a_O0) | gelu(a_O2) replace the pre-activations in `act` (enf_train.hip forms X^T delta)
+  int ybar_half;         // forward only (ENF_STAGE_YBAR_HALF): `ybar` holds bf16 rows
   int NQ, O;             // NQ = B*N queries
   float inv_hd;          // 1 / (H * true num_hidden)
 };
@@ -31,6 +32,15 @@ struct TailArgs {
 template <int NT> DEV void load_rows(f32x4 (&X)[NT], const float* row, int quad) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) X[t] = *reinterpret_cast<const f32x4*>(row + 16 * t + 4 * quad);
+}
+// the same from bf16 rows (two values per word, low half first)
+template <int NT> DEV void load_rows_half(f32x4 (&X)[NT], const unsigned short* row, int quad) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const uint2 w = *reinterpret_cast<const uint2*>(row + 16 * t + 4 * quad);
+    X[t] = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                 __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+  }
 }
 template <int NT> DEV void store_rows(const f32x4 (&X)[NT], float* row, int quad) {
 #pragma unroll
@@ -125,7 +135,7 @@ DEV void tail_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, cha
 // two, or nothing); the 2-slot pipeline only uses the first stage of NX1.
 template <int D, int H, bool BF16, bool SAVE, bool LA2, typename NX1, typename NX2>
 DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLayout& L, const float* cst, Pipe& P,
-                      char* ring, unsigned next, unsigned next2, int lane, int quad, float inv_hd, bool save_ok = true) {
+                      char* ring, unsigned next, unsigned next2, int lane, int quad, float inv_hd, bool save_ok = true, bool y_half = false) {
   using T = TailCfg<D, H, BF16>;
   constexpr int KB = T::KB, KBH = T::KBH, NT = T::NT, NTH = T::NTH, HD = T::HD;
   using PTB = Pan<KBH, NTH, BF16>; using PO0 = Pan<KBH, NT, BF16>; using PO2 = Pan<KB, NT, BF16>; using PO4 = Pan<KB, 2, BF16>;
@@ -133,7 +143,8 @@ DEV void tail_forward(f32x4 (&o4)[2], const float* yrow, float* act, const EnfLa
   const float* c_bB = cst, *c_bF1 = cst + HD, *c_bO0 = cst + 2 * HD, *c_bO2 = cst + 2 * HD + D, *c_bO4 = cst + 2 * HD + 2 * D;
   Frags<BF16, KBH> FH;
   f32x4 a[NTH];
-  load_rows<NTH>(a, yrow, quad);
+  if (y_half) load_rows_half<NTH>(a, reinterpret_cast<const unsigned short*>(yrow), quad);     // (yrow: the caller's row pointer in bf16 units)
+  else load_rows<NTH>(a, yrow, quad);
   make_frags<BF16, KBH>(FH, a);
 #pragma unroll
   for (int t = 0; t < NTH; ++t) a[t] = rowvec(c_bB, t, quad);
@@ -210,8 +221,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_tail_fwd_kernel(TailArgs A) {
   } else first_stage<T::ST_TB>(P, ring, (unsigned)A.L.atb, wave, lane);
   f32x4 o4[2];
   // SAVE: the pre-activations go to the workspace so that the backward that follows need not recompute this chain
-  tail_forward<D, H, BF16, SAVE, LA2, NoPan, NoPan>(o4, A.ybar + (size_t)qi * T::HD, SAVE ? A.act + (size_t)qi * T::ACT : nullptr, A.L,
-                                                    cst, P, ring, NO_STAGE, NO_STAGE, lane, quad, A.inv_hd);
+  const bool yh = !SAVE && A.ybar_half;
+  const float* yrow = yh ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(A.ybar) + (size_t)qi * T::HD)
+                         : A.ybar + (size_t)qi * T::HD;
+  tail_forward<D, H, BF16, SAVE, LA2, NoPan, NoPan>(o4, yrow, SAVE ? A.act + (size_t)qi * T::ACT : nullptr, A.L,
+                                                    cst, P, ring, NO_STAGE, NO_STAGE, lane, quad, A.inv_hd, true, yh);
   if (q0 + col < A.NQ) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -455,6 +469,8 @@ extern "C" int enf_launch_tail_wg(const EnfDims& m, const EnfLayout& L, const ch
   TailArgs A;
   A.target = nullptr; A.loss = nullptr; A.gscale = 0.f; A.inv_n = 0.f;
   A.tdel = tdel;
+  A.ybar_half = (!bwd && (opt & 2) && m.bf16) ? 1 : 0;
+  opt &= 1;
   A.ybar = ybar; A.blob = blob; A.L = L; A.out = out; A.dout = dout; A.dybar = dybar; A.delta = delta; A.act = act;
   A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.Ht * m.Dt);
 #define ENF_CASE(DD, HH)                                                                   \
@@ -475,6 +491,7 @@ extern "C" int enf_launch_tail_loss(const EnfDims& m, const EnfLayout& L, const 
   if (m.OB != 1) return ENF_EUNSUPPORTED;
   TailArgs A;
   A.ybar = ybar; A.blob = blob; A.L = L; A.out = nullptr; A.dout = nullptr; A.dybar = dybar; A.delta = delta; A.act = act; A.tdel = nullptr;
+  A.ybar_half = 0;
   A.target = target; A.loss = loss; A.gscale = gscale; A.inv_n = 1.0f / ((float)m.B * (float)m.N * (float)m.O);
   A.NQ = m.B * m.N; A.O = m.O; A.inv_hd = 1.0f / (float)(m.Ht * m.Dt);
 #define ENF_CASE(DD, HH)                                                                   \

@@ -94,8 +94,11 @@ class _EnfFunction(torch.autograd.Function):
         dev = p.device
         out = torch.empty((B, N, model.num_out), device=dev, dtype=torch.float32)
         HD = model._Hp * model._Dp
-        ybar = torch.empty((B, N, HD), device=dev, dtype=torch.float32)
-        lse = torch.empty((B, N, model._Hp), device=dev, dtype=torch.float32)
+        # no input needs a gradient (a decode): nothing will read this call's ybar / lse -- they stay in the workspace, and the pair
+        # kernel may hand ybar to the tail as bf16 (ENF_STAGE_YBAR_HALF, include/enf_hip.h: same `out`, half the bytes)
+        no_grad = not any(ctx.needs_input_grad[:4])
+        ybar = None if no_grad else torch.empty((B, N, HD), device=dev, dtype=torch.float32)
+        lse = None if no_grad else torch.empty((B, N, model._Hp), device=dev, dtype=torch.float32)
         ws = model._workspace(desc, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         # a backward follows when an input needs a gradient: stash the tail's pre-activations for it (ENF_STAGE_TAIL_SAVE)
@@ -106,7 +109,7 @@ class _EnfFunction(torch.autograd.Function):
         lt_key = (ws.data_ptr(), packed.data_ptr(), B, Z) + tuple((t.data_ptr(), t._version) for t in (p_, a_) + ((s_,) if s_ is not None else ()))
         held = model._lt_held.get(ws.data_ptr())
         reuse_lt = held is not None and held[0] == lt_key and held[1] == model._ws_tags.get(ws.data_ptr())
-        stages = (14 if reuse_lt else 15) | (16 if ctx.tail_saved else 0)
+        stages = (14 if reuse_lt else 15) | (16 if ctx.tail_saved else 0) | (64 if no_grad else 0)
         _lib.launch(dev, lib.enf_forward_stages, ctypes.byref(desc), _ptr(xb), xstride, _ptr(p_), _ptr(a_), _ptr(s_), _ptr(packed),
                                           _ptr(out), _ptr(ybar), _ptr(lse), _ptr(ws), ws.numel(), stages, st)
         ctx.ws_tag = model._ws_touch(ws)      # backward may reuse the latent table if nothing else used the workspace
@@ -115,7 +118,8 @@ class _EnfFunction(torch.autograd.Function):
         ctx.model = model
         ctx.has_sigma = sigma is not None
         ctx.xstride = xstride
-        ctx.save_for_backward(xb, p_, a_, s_ if s_ is not None else p_.new_empty(0), packed, ybar, lse)
+        if not no_grad:
+            ctx.save_for_backward(xb, p_, a_, s_ if s_ is not None else p_.new_empty(0), packed, ybar, lse)
         return out
 
     @staticmethod

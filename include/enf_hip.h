@@ -163,6 +163,11 @@ int enf_forward(const EnfDesc* d, const float* x, int64_t x_bstride, const float
                                   side stream behind the pair kernel; pass ENF_BWD_REUSE_PREPARED to that backward.  The
                                   pending work is recorded against this workspace: any later call on the same workspace
                                   joins it first, a call on another workspace neither sees nor consumes it */
+#define ENF_STAGE_YBAR_HALF 64u /* with ENF_STAGE_PAIR | ENF_STAGE_TAIL in ONE call, bf16 mode, `ybar` == NULL: nothing after this call reads
+                                   its `ybar` (a decode: no backward follows), so the pair kernel may hand it to the tail as bf16 in the
+                                   workspace -- half the bytes of the largest tensor of a forward; the tail rounds `ybar` to bf16 for its
+                                   first matrix product anyway, so `out` is the same bit for bit.  Ignored where it does not apply
+                                   (f32 mode, ENF_STAGE_TAIL_SAVE, the split z-fold variant, a caller-owned `ybar`). */
 int enf_forward_stages(const EnfDesc* d, const float* x, int64_t x_bstride, const float* p, const float* a,
                        const float* sigma, const void* packed, float* out, float* ybar, float* lse,
                        void* workspace, size_t workspace_bytes, unsigned stages, void* stream);

@@ -202,3 +202,38 @@ def test_latent_table_is_reused_only_for_the_same_latents(cuda, pair_variant):
             assert calls[-1] & 1 == 1 and not torch.equal(other, moved)
     finally:
         lib.enf_forward_stages = orig
+
+
+@pytest.mark.parametrize("B,N,Z", [(6, 4096, 64), (3, 300, 16)])
+def test_half_precision_hand_off_to_the_tail_changes_no_bit(cuda, B, N, Z, pair_variant):
+    """ENF_STAGE_YBAR_HALF (include/enf_hip.h): a forward that no backward follows hands ybar to the tail as bf16 through the workspace.
+    The tail rounds ybar to bf16 for its first matrix product anyway, so `out` must equal the fp32 hand-off's bit for bit (bf16 mode; both
+    kernels that write ybar themselves: the z-fold with >= 192 query tiles and the latent-split one; the split z-fold ignores the flag)."""
+    import ctypes
+    from enf_pde_amd import _lib
+    cfg = make_cfg("rel_pos_periodic", D=128, H=2, C=16, O=1)
+    prm = R.init_params(31, cfg, jitter=0.1)
+    x, p, a, s = make_inputs(cfg, B, N, Z, 32)
+    nef = build_nef(cfg, "bf16")
+    params = nef.load_params(prm, device=cuda)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=cuda)
+    tx, tp, ta, ts = t(x), t(p), t(a), t(s)
+    calls = []
+    lib = _lib.load()
+    orig = lib.enf_forward_stages
+
+    class Spy:
+        def __call__(self, *args):
+            calls.append(int(args[-2]))
+            return orig(*args)
+    try:
+        lib.enf_forward_stages = Spy()
+        with torch.no_grad():
+            half = nef.apply(params, tx, tp, ta, ts)
+        full = nef.apply(params, tx, tp.clone().requires_grad_(True), ta, ts).detach()
+    finally:
+        lib.enf_forward_stages = orig
+    assert calls[0] & 64 and not calls[1] & 64
+    assert torch.isfinite(half).all() and torch.equal(half, full)
+    ref = R.nef_apply(prm, cfg, x[:1, :64], p[:1], a[:1], s[:1])
+    assert np.abs(half[:1, :64].cpu().numpy() - ref).max() < 3e-2 * np.abs(ref).max()
