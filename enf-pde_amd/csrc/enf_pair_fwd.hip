@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * PairWaves<ZFOLD>::NW, 2) void enf_pair_fwd_ker
       for (int t = 0; t < NT; ++t) {
         f32x4 o = Y[h][t];
         o[0] -= cs; o[1] -= cs; o[2] -= cs; o[3] -= cs;
-        if (A.ybar_half) {      // (wave-uniform) round to nearest even, as the tail's make_frags would
+        if (!MASKS && BF16 && A.ybar_half) {      // (wave-uniform; masked passes are training passes) round to nearest even, as the tail's make_frags would
           unsigned short* yh = reinterpret_cast<unsigned short*>(A.ybar) + ((size_t)b * A.N + n0 + col) * (H * D);
           *reinterpret_cast<uint2*>(yh + h * D + 16 * t + 4 * quad) = uint2{bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3])};
         } else {
