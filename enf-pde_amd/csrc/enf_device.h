@@ -400,16 +400,37 @@ DEV __amdgpu_buffer_rsrc_t make_blob_rsrc(const char* blob, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(blob), 0, bytes, 0x00020000);
 }
 
+#ifndef ENF_STAGE_CONTIG
+#define ENF_STAGE_CONTIG 1
+#endif
+// pieces I .. PPW-1 of a wave's run (the offset field wants a constant: unrolled by recursion)
+template <int BYTES, bool FULL, int I, int PPW>
+DEV void stage_pieces(__amdgpu_buffer_rsrc_t rs, lds_ptr_t dst, int voff, unsigned soff, int base) {
+  if constexpr (I < PPW) {
+    if (FULL || base + I * 1024 < BYTES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, I * 1024, 0);
+    stage_pieces<BYTES, FULL, I + 1, PPW>(rs, dst, voff, soff, base);
+  }
+}
 template <int BYTES, int NW = NWAVES>
 DEV void stage_issue(__amdgpu_buffer_rsrc_t rs, unsigned src_off, char* dst, int wave, int lane) {
   static_assert(BYTES % 1024 == 0 && BYTES <= STAGE_MAX, "stage size");
   constexpr int PIECES = BYTES / 1024;                  // 1 KB per wave-instruction
+#if ENF_STAGE_CONTIG
+  // a wave copies PPW CONSECUTIVE kilobytes: the piece index then fits the instruction's 12-bit offset field (which moves the source and
+  // the LDS side alike), so a stage needs ONE scalar source offset and ONE M0 value per wave.  With the pieces interleaved over the waves
+  // (8 KB apart) every piece had its own pair, hipcc hoisted all of them out of the tile loop and spilled them: ~60 v_readlane_b32 per
+  // K3 tile (round 3, scripts/r03_ab_vs_head.sh)
+  constexpr int PPW = (PIECES + NW - 1) / NW;
+  const int base = wave * (PPW * 1024);
+  stage_pieces<BYTES, PIECES % NW == 0, 0, PPW>(rs, (lds_ptr_t)(dst + base), lane * 16, src_off + base, base);
+#else
 #pragma unroll
   for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
     const int piece = (i * NW + wave) * 1024;
     if (PIECES % NW == 0 || piece < BYTES)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + piece), 16, lane * 16, src_off + piece, 0, 0);
   }
+#endif
 }
 DEV void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
