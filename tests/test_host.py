@@ -123,6 +123,23 @@ def test_check_desc_and_error_mapping(lib):
     assert lib.enf_workspace_bytes(ctypes.byref(c3)) > lib.enf_workspace_bytes(ctypes.byref(c3ls))
     # NULL buffers are rejected before anything touches the (absent) GPU
     assert lib.enf_forward(ctypes.byref(ok), None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
+    # ... by the one-call inner step and the one-call training backward too (every pointer NULL, every number zero)
+    def zeros(fn):
+        out = []
+        for t in fn.argtypes[1:]:
+            if t in (ctypes.c_float, ctypes.c_double):
+                out.append(0.0)
+            elif t in (ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint, ctypes.c_size_t, ctypes.c_longlong):
+                out.append(0)
+            else:
+                out.append(None)
+        return out
+    assert lib.enf_fit_step(ctypes.byref(ok), *zeros(lib.enf_fit_step)) == -1
+    assert lib.enf_backward_all(ctypes.byref(ok), *zeros(lib.enf_backward_all)) == -1
+    assert lib.enf_backward_all_scratch_bytes(ctypes.byref(ok), 1) > 0
+    bad = _lib.make_desc(2, 16, 16, 2, 64, 8, 1, 2, 9, 1, 0)              # an invalid descriptor is refused before the arguments are looked at
+    assert lib.enf_fit_step(ctypes.byref(bad), *zeros(lib.enf_fit_step)) < 0
+    assert lib.enf_backward_all_scratch_bytes(ctypes.byref(bad), 1) == 0
 
 
 def _partition(desc):
