@@ -102,6 +102,9 @@
 #ifndef ENF_K3_INV_SPECIALISED
 #define ENF_K3_INV_SPECIALISED 1
 #endif
+#ifndef ENF_K3_STORE_SPEC
+#define ENF_K3_STORE_SPEC 1
+#endif
 #ifndef ENF_K3_STATIC_PRIO
 #define ENF_K3_STATIC_PRIO 0
 #endif
@@ -123,6 +126,23 @@ struct PairBwdArgs {
   int B, N, Z, dx, inv, use_window, nsplit;
   int xcd_remap;                        // ZF: 1-D grid, the nsplit workgroups of a latent adjacent on one XCD (launch_pair_bwd)
 };
+
+// The STORE instantiation's 7 + 4 H buffer pointers, fetched from the kernel-argument segment where they are used (s_load_dwordx2 +
+// lgkmcnt).  Read as `A.store[i]` hipcc loads all of them once, cannot keep 30 scalar registers across the tile loop and spills them to
+// scratch: 15 scratch reloads per tile, each with an `s_waitcnt vmcnt(0)` that also waits for the LDS-DMA stage in flight.
+#ifndef ENF_K3_STORE_SLOAD
+#define ENF_K3_STORE_SLOAD 1
+#endif
+DEV void* k3_store_ptr(const PairBwdArgs& A, int i) {
+#if ENF_K3_STORE_SLOAD
+  void* p;
+  const unsigned off = (unsigned)(offsetof(PairBwdArgs, store) + 8 * i);
+  asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(p) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "s"(off));
+  return p;
+#else
+  return A.store[i];
+#endif
+}
 
 // Debug build only (-DENF_STAMPS): s_memtime stamps of the first tiles of one workgroup (scripts/stamps_k3.py)
 #ifdef ENF_STAMPS
@@ -628,7 +648,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 acc[NT];
       rff_embed<D, BF16>(acc, inv, c_acv, lane, quad, phv);
       make_frags<BF16, KB>(F, acc);
-      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EV], srow, D, F, quad);
+      if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_EV), srow, D, F, quad);
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(acc, F, P, ring, pV1, LA ? STAGE_RS2 : pF, true, lane, c_bv1);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         }
       if (STORE && A.masks) relu_mask = maskv;
       make_frags<BF16, KB>(F, acc);
-      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_G1], srow, D, F, quad);
+      if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_G1), srow, D, F, quad);
       if constexpr (ZF) panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS, LA>(a3, F, P, ring, pF, LA ? (ENF_K3_DN_LATE ? gM : STAGE_RS2 | (unsigned)PANEL_DD) : STAGE_RS2, true, lane, c_bf);
       else panel_gemm<KB, NT, BF16, ST_GB, NWAVES, INIT_BIAS>(a3, F, P, ring, pF, pGB, true, lane, c_bf);
 #if ENF_K3_A3_FUSED
@@ -683,7 +703,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       ln_stats<NT>(nh, mu1, r1, A.inv_d);
       ln_apply<NT>(nh, mu1, r1);
       make_frags<BF16, KB>(F, nh);
-      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_NH], srow, D, F, quad);
+      if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_NH), srow, D, F, quad);
 #if ENF_K3_PARK
       A3P.park(a3);
 #endif
@@ -842,7 +862,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       {
         Frags<BF16, KB> FV;
         make_frags<BF16, KB>(FV, v);
-        if (swrite) store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h], srow, D, FV, quad);
+        if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_HEAD0 + 4 * h), srow, D, FV, quad);
         panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_BIAS>(a5, FV, P, ring, pM, gM, true, lane, c_bm);
       }
       BSTAMP(4 + 6 * h);
@@ -918,7 +938,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       {
         Frags<BF16, KB> FA;
         make_frags<BF16, KB>(FA, dy);
-        if (swrite) store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 1], srow, D, FA, quad);
+        if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_HEAD0 + 4 * h + 1), srow, D, FA, quad);
         float part[NT];
         panel_gemm_flip<KB, NT, BF16, ST_GG, NW, true, INIT_ZERO>(
             v, FA, P, ring, gM, gGB + h * PANEL_GG, lane, [](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
@@ -969,8 +989,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
           if constexpr (BF16) { Fg.f[m] = FG.f[2 * m]; Fb.f[m] = FG.f[2 * m + 1]; }
           else { Fg.f[2 * m] = FG.f[4 * m]; Fg.f[2 * m + 1] = FG.f[4 * m + 1]; Fb.f[2 * m] = FG.f[4 * m + 2]; Fb.f[2 * m + 1] = FG.f[4 * m + 3]; }
         }
-        store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 2], srow, D, Fg, quad);
-        store_frags<BF16, KB>(A.store[ENF_S_HEAD0 + 4 * h + 3], srow, D, Fb, quad);
+        store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_HEAD0 + 4 * h + 2), srow, D, Fg, quad);
+        store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_HEAD0 + 4 * h + 3), srow, D, Fb, quad);
       }
       if (h + 1 < H) panel_gemm<2 * KB, NT, BF16, ST_GB>(dnh, FG, P, ring, gGB + h * PANEL_GG, pGB + (h + 1) * PANEL_GB, true, lane);
       else panel_gemm<2 * KB, NT, BF16, ST_DD>(dnh, FG, P, ring, gGB + h * PANEL_GG, gF, true, lane);
@@ -1004,7 +1024,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         K3_SCHED_FENCE();
       }
       make_frags<BF16, KB>(F, dnh);
-      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA3], srow, D, F, quad);
+      if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_DA3), srow, D, F, quad);
       f32x4 acc[NT];
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(acc, F, P, ring, gF, LA ? pQ1 : gV1, true, lane);       // d g1
 #pragma unroll
@@ -1013,7 +1033,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
         for (int i = 0; i < 4; ++i)       // d a2
           acc[t][i] = ((relu_mask >> (4 * t + i)) & 1u) ? acc[t][i] : 0.f;
       make_frags<BF16, KB>(F, acc);
-      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA2], srow, D, F, quad);
+      if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_DA2), srow, D, F, quad);
       panel_gemm<KB, NT, BF16, ST_DD, NWAVES, INIT_ZERO, LA>(acc, F, P, ring, gV1, LA ? gQ1 : pQ1, true, lane);      // d E_v
       f32x4 Ev[NT];
       rff_embed<D, BF16>(Ev, inv, c_acv, lane, quad, phv);                                                           // recomputed
@@ -1033,7 +1053,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       f32x4 E[NT];
       rff_embed<D, BF16>(E, inv, c_acq, lane, quad, phq);
       make_frags<BF16, KB>(F, E);
-      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_EQ], srow, D, F, quad);
+      if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_EQ), srow, D, F, quad);
       f32x4 acc[NT];
       float dl[H][4];                     // dlogit of the 4 queries this lane's flipped rows hold
 #pragma unroll
@@ -1093,7 +1113,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void enf_pair_bwd_kernel(PairBwdArgs A
       }
       Frags<BF16, KB> FA;
       make_frags<BF16, KB>(FA, acc);
-      if (swrite) store_frags<BF16, KB>(A.store[ENF_S_DA1], srow, D, FA, quad);
+      if (swrite) store_frags<BF16, KB>(k3_store_ptr(A, ENF_S_DA1), srow, D, FA, quad);
 #if ENF_K3_PREFETCH
       if (more) prefetch(ti + 1);          // the next tile's coordinates / lse land under this stage
 #endif
@@ -1271,6 +1291,11 @@ extern "C" int enf_launch_pair_bwd(const EnfDims& m, const EnfLayout& L, const c
     }
     if (m.D == 64 && m.H == 2 && m.inv == ENF_INV_PONITA) return launch_pair_bwd<64, 2, true, false, true, ENF_INV_PONITA>(A, st);
   }
+#if ENF_K3_STORE_SPEC
+  // the training path's kernel (activation store) of the headline configs likewise
+  if (store && m.bf16 && m.dx == 2 && m.D == 128 && m.H == 2 && m.inv == ENF_INV_REL_POS_PERIODIC)
+    return launch_pair_bwd<128, 2, true, true, false, ENF_INV_REL_POS_PERIODIC>(A, st);
+#endif
 #endif
   ENF_CASE(128, 2)
   ENF_CASE(64, 2)
