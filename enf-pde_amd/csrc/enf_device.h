@@ -448,8 +448,15 @@ constexpr unsigned STAGE_RS2 = 0x80000000u;
 struct Pipe { __amdgpu_buffer_rsrc_t rs, rs2; int cur; int wave; bool early; };
 template <int BYTES, int NW = NWAVES>
 DEV void stage_issue_p(const Pipe& P, unsigned src_off, char* dst, int lane) {
+#ifdef ENF_PIPE_ONE_RS       // a translation unit whose kernels stream from the weight blob only (enf_tail.hip).  With the choice below compiled
+  // in, hipcc kept the whole Pipe of the tail's 2-slot kernels in scratch memory (64 bytes, no register spilled): the resource descriptor
+  // came back through scratch_load + v_readfirstlane in front of every stage, behind an `s_waitcnt vmcnt(0)` that also waits for the
+  // LDS-DMA stage in flight.  (The pair kernels, which do use both resources, keep theirs in scalar registers.)
+  stage_issue<BYTES, NW>(P.rs, src_off, dst, P.wave, lane);
+#else
   if (src_off & STAGE_RS2) stage_issue<BYTES, NW>(P.rs2, src_off & ~STAGE_RS2, dst, P.wave, lane);
   else stage_issue<BYTES, NW>(P.rs, src_off, dst, P.wave, lane);
+#endif
 }
 DEV void stage_open(const Pipe& P) { if (P.early) { stage_wait(); __syncthreads(); } }
 DEV void stage_close(Pipe& P) { if (!P.early) { stage_wait(); __syncthreads(); } P.cur ^= 1; }
@@ -484,17 +491,17 @@ template <int KBIN, int MTOUT, bool BF16> struct PanelCfg {
 // slot right behind the barrier that retires it -- so it streams under the vector-ALU epilogue that follows this call and
 // under the next stage's MFMAs, not under those MFMAs alone (a D x D stage is ~1000 cycles of MFMAs for the two waves of a
 // SIMD, the DMA of its successor ~3000: without this every stage that follows an epilogue waits for its panel).
-template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES, int INIT = INIT_ACC, bool LA = false>
-DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned next,
-                    bool active, int lane, const float* bias = nullptr) {
+// (the stages of a panel are unrolled by recursion: the stage index is a constant in every instruction's offset)
+template <int SP, int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW, int INIT, bool LA>
+DEV void panel_gemm_stages(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned next,
+                           bool active, int lane, const float* bias) {
   using C = PanelCfg<KBIN, MTOUT, BF16>;
-  static_assert(!LA || C::SPP == 1, "look-ahead staging: single-stage panels");
-#pragma unroll
-  for (int sp = 0; sp < C::SPP; ++sp) {
+  if constexpr (SP < C::SPP) {
+    constexpr int sp = SP;
     stage_open(P);
     if constexpr (LA) {}
-    else if (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
-    else if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane);
+    else if constexpr (sp + 1 < C::SPP) stage_issue_p<C::STAGE, NW>(P, panel + (sp + 1) * C::STAGE, ring + (P.cur ^ 1) * STAGE_MAX, lane);
+    else { if (next != NO_STAGE) stage_issue_p<NEXT_BYTES, NW>(P, next, ring + (P.cur ^ 1) * STAGE_MAX, lane); }
     if (active) gemm_stage<BF16, KBIN, C::MTS, INIT>(&acc[sp * C::MTS], F, ring + P.cur * STAGE_MAX, lane, bias + 16 * sp * C::MTS);
     else if constexpr (INIT != INIT_ACC) {        // a wave that only keeps the barrier cadence still gets defined values
 #pragma unroll
@@ -504,7 +511,15 @@ DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, ch
     }
     if constexpr (LA) stage_close_la<NEXT_BYTES, NW>(P, ring, next, lane);
     else stage_close(P);
+    panel_gemm_stages<SP + 1, KBIN, MTOUT, BF16, NEXT_BYTES, NW, INIT, LA>(acc, F, P, ring, panel, next, active, lane, bias);
   }
+}
+template <int KBIN, int MTOUT, bool BF16, int NEXT_BYTES, int NW = NWAVES, int INIT = INIT_ACC, bool LA = false>
+DEV void panel_gemm(f32x4 (&acc)[MTOUT], const Frags<BF16, KBIN>& F, Pipe& P, char* ring, unsigned panel, unsigned next,
+                    bool active, int lane, const float* bias = nullptr) {
+  using C = PanelCfg<KBIN, MTOUT, BF16>;
+  static_assert(!LA || C::SPP == 1, "look-ahead staging: single-stage panels");
+  panel_gemm_stages<0, KBIN, MTOUT, BF16, NEXT_BYTES, NW, INIT, LA>(acc, F, P, ring, panel, next, active, lane, bias);
 }
 
 // panel_gemm that additionally hands every out-tile's FLIPPED product to `flip(tile, acc)`

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include "enf_layout.h"
 #include "enf_launch.h"
+#define ENF_PIPE_ONE_RS 1      // the tail streams from the weight blob only (enf_device.h: stage_issue_p)
 #include "enf_device.h"
 
 struct TailArgs {

@@ -2,7 +2,7 @@
 # quick same-box A/B of the working tree against the previous commit (variants/libenf_base.so): forward / golden parity, then steps + a kernel trace
 O=gpurun_out/r03
 mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_forward.py tests/test_gpu_golden.py -m gpu -x -q > $O/q_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -2 $O/q_tests.log
+timeout -k 10 900 python -m pytest tests/test_gpu_forward.py tests/test_gpu_golden.py tests/test_gpu_backward.py tests/test_gpu_weight_grads.py tests/test_gpu_layers.py -m gpu -x -q > $O/q_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -2 $O/q_tests.log
 [ $rc = 0 ] || exit 1
 for v in base default base default base default; do
   L=variants/libenf_$v.so; [ $v = default ] && L=
