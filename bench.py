@@ -302,6 +302,50 @@ def events_leg(c, m, coords, dcoords, img, device, steps=100):
             "clock": "hipEvent pairs around each step on the launch stream, rank 0, after the timed region"}
 
 
+def graph_leg(c, m, coords, dcoords, img, device, steps=100):
+    """--graph-leg (off by default): the whole fit + decode step captured ONCE as a hipGraph (torch.cuda.graph: the library's launches go to
+    torch's current stream, its side stream is forked from and joined back into it inside each call, so the capture sees every kernel)
+    and replayed `steps` times: what the step costs without the host's launch path and with the graph's tighter kernel spacing.
+    Not used for `value`."""
+    out = {}
+    try:
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step(c, m, coords, dcoords, img)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, recon = step(c, m, coords, dcoords, img)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize(device)
+        l_eager, r_eager = step(c, m, coords, dcoords, img)
+        torch.cuda.synchronize(device)
+        g.replay()
+        torch.cuda.synchronize(device)
+        out["max_abs_diff_vs_eager"] = float((recon - r_eager).abs().max())
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ev[0].record()
+        for i in range(steps):
+            g.replay()
+            ev[i + 1].record()
+        torch.cuda.synchronize(device)
+        ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize(device)
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        out.update({"steps": steps, "ms_median": round(ts[steps // 2], 4), "ms_min": round(ts[0], 4), "ms_wall": round(wall, 4),
+                    "qps_wall_per_gpu": round(c["B"] * points_per_signal(c) / (wall * 1e-3), 1), "launch": "hipGraph replay of one captured step"})
+    except Exception as e:        # a capture the runtime refuses must not cost the bench line
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------- roofline
 def _time_launches(fn, device, iters):
     for _ in range(3):
@@ -606,6 +650,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs")
     ap.add_argument("--kernel-iters", type=int, default=20, help="launches per timed per-kernel leg")
     ap.add_argument("--events-steps", type=int, default=100, help="steps of the per-step event timing (median) reported beside `value`; 0 = skip")
+    ap.add_argument("--graph-leg", action="store_true", help="also time the step as a captured hipGraph (reported under timing.graph; `value` unchanged)")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the field-MSE-vs-oracle check of the fitted latents")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run ONLY the per-kernel legs and print them (for rocprofv3 --kernel-trace --stats: the profile then "
@@ -676,6 +721,8 @@ def main():
     if rank == 0:
         if args.events_steps > 0:
             result["timing"]["events"] = events_leg(c, m, coords, dcoords, img, device, args.events_steps)
+        if args.graph_leg and not c.get("rollout"):
+            result["timing"]["graph"] = graph_leg(c, m, coords, dcoords, img, device, max(args.events_steps, 20))
         if not args.no_accuracy:
             _, lat_fit = fit(m, coords, img)
             result["accuracy"] = accuracy_leg(c, m, dcoords, lat_fit, device)
