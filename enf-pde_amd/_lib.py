@@ -17,7 +17,7 @@ EXPORTS = ["enf_abi_version", "enf_strerror", "enf_invariant_dim", "enf_invarian
            "enf_packed_weight_bytes", "enf_pack_weights", "enf_workspace_bytes", "enf_forward",
            "enf_backward_latents", "enf_backward_latents_ex", "enf_forward_stages", "enf_lt_layout", "enf_lt_layout_ext", "enf_pack_pair", "enf_pair_forward",
            "enf_pair_backward", "enf_pair_backward_ex", "enf_pair_scratch_bytes", "enf_pair_variant", "enf_pair_partition", "enf_backward_weights", "enf_backward_weights_scratch_bytes",
-           "enf_backward_all", "enf_backward_all_scratch_bytes", "enf_fit_step",
+           "enf_backward_all", "enf_backward_all_scratch_bytes", "enf_fit_step", "enf_fit_inputs",
            "enf_mse_value_grad",
            "enf_ode_conv_forward", "enf_ode_conv_backward_basis", "enf_ode_conv_backward_weight", "enf_ode_conv_backward_weight_scratch_bytes", "enf_ode_poly_num_features", "enf_ode_poly_forward",
            "enf_ode_poly_backward", "enf_ode_vec_readout_forward", "enf_ode_vec_readout_backward", "enf_ode_block_supported", "enf_ode_block_scratch_bytes", "enf_ode_block_forward", "enf_ode_block_backward",
@@ -52,6 +52,10 @@ class EnfSgdSegment(ctypes.Structure):
 
 
 ENF_SGD_MAX_SEGMENTS = 4
+
+
+class EnfFitComponent(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("width", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class EnfError(RuntimeError):
@@ -122,6 +126,7 @@ def _bind(path, test_hooks):
     lib.enf_pack_pair.argtypes = [dp, ctypes.POINTER(vp), vp, vp]
     lib.enf_mse_value_grad.argtypes = [vp, vp, sz, ctypes.c_float, vp, vp, vp]
     lib.enf_meta_sgd_update.argtypes = [ctypes.c_int, ctypes.POINTER(EnfSgdSegment), ctypes.c_float, vp]
+    lib.enf_fit_inputs.argtypes = [ctypes.c_int, ctypes.POINTER(EnfFitComponent)] + [ctypes.c_int32] * 7 + [vp] * 7
     lib.enf_ode_conv_forward.argtypes = [ci, ci, ci, ci, vp, vp, i64, i64, vp, vp, vp, vp]
     lib.enf_ode_conv_backward_basis.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp]
     lib.enf_ode_conv_backward_weight_scratch_bytes.restype = sz

@@ -69,3 +69,63 @@ extern "C" int enf_meta_sgd_update(int nseg, const EnfSgdSegment* segs, float sc
   hipLaunchKernelGGL(enf_meta_sgd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
   return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
 }
+
+// enf_fit_inputs: the inner loop's setup in one launch (include/enf_hip.h) -- broadcast of the latent initialisation over the signals,
+// gather of the S + 1 sampled coordinate / target sets, zeroed loss accumulators.  One flat index space over the five outputs.
+struct FitInArgs {
+  EnfFitComponent comp[ENF_SGD_MAX_SEGMENTS];
+  int ncomp, B, Z, N, Ns, S1, dx, O;
+  const float* coords; const float* img; const int64_t* masks;
+  float* xs; float* ys; float* losses;
+};
+
+__global__ __launch_bounds__(256) void enf_fit_inputs_kernel(FitInArgs A) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < ENF_SGD_MAX_SEGMENTS; ++k) {
+    if (k < A.ncomp) {
+      const int64_t per = (int64_t)A.Z * A.comp[k].width, n = per * A.B;
+      if (i < n) { A.comp[k].dst[i] = A.comp[k].src[i % per]; return; }
+      i -= n;
+    }
+  }
+  const int64_t nx = (int64_t)A.S1 * A.Ns * A.dx;
+  if (i < nx) {                                   // xs[s][q][c] = coords[masks[q][s]][c]
+    const int c = (int)(i % A.dx);
+    const int64_t sq = i / A.dx, q = sq % A.Ns, s = sq / A.Ns;
+    A.xs[i] = A.coords[A.masks[q * A.S1 + s] * A.dx + c];
+    return;
+  }
+  i -= nx;
+  const int64_t ny = (int64_t)A.S1 * A.B * A.Ns * A.O;
+  if (i < ny) {                                   // ys[s][b][q][o] = img[b][masks[q][s]][o]
+    const int o = (int)(i % A.O);
+    int64_t r = i / A.O;
+    const int64_t q = r % A.Ns; r /= A.Ns;
+    const int64_t b = r % A.B, s = r / A.B;
+    A.ys[i] = A.img[(b * A.N + A.masks[q * A.S1 + s]) * A.O + o];
+    return;
+  }
+  i -= ny;
+  if (i < A.S1) A.losses[i] = 0.f;
+}
+
+extern "C" int enf_fit_inputs(int ncomp, const EnfFitComponent* comps, int32_t B, int32_t Z, int32_t N, int32_t Ns, int32_t S1, int32_t dx,
+                              int32_t O, const float* coords, const float* img, const int64_t* masks, float* xs, float* ys, float* losses,
+                              void* stream) {
+  if (ncomp < 1 || ncomp > ENF_SGD_MAX_SEGMENTS || !comps || !coords || !img || !masks || !xs || !ys || !losses) return ENF_EINVAL;
+  if (B < 1 || Z < 1 || N < 1 || Ns < 1 || S1 < 1 || dx < 1 || O < 1) return ENF_EDIM;
+  FitInArgs A{};
+  int64_t total = 0;
+  for (int k = 0; k < ncomp; ++k) {
+    if (!comps[k].src || !comps[k].dst || comps[k].width < 1) return ENF_EINVAL;
+    A.comp[k] = comps[k];
+    total += (int64_t)B * Z * comps[k].width;
+  }
+  A.ncomp = ncomp; A.B = B; A.Z = Z; A.N = N; A.Ns = Ns; A.S1 = S1; A.dx = dx; A.O = O;
+  A.coords = coords; A.img = img; A.masks = masks; A.xs = xs; A.ys = ys; A.losses = losses;
+  total += (int64_t)S1 * Ns * dx + (int64_t)S1 * B * Ns * O + S1;
+  hipLaunchKernelGGL(enf_fit_inputs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+  return hipGetLastError() == hipSuccess ? ENF_OK : ENF_ELAUNCH;
+}
+

@@ -22,6 +22,39 @@ def make_masks(num_coords, num_sampled, num_inner_steps, generator=None, device=
     return torch.stack(cols, dim=1).to(device)
 
 
+FUSED_FIT_INPUTS = __import__("os").environ.get("ENF_FIT_INPUTS") != "0"
+
+
+def _fit_inputs(latents0, coords, img, masks):
+    """enf_fit_inputs (include/enf_hip.h): (lat, xs_all, ys_all, losses) of inner_loop in one launch, or None where the arguments are not
+    what the kernel takes (fp32, contiguous, on one GPU, at most four latent components of leading dimension 1)."""
+    ts = list(latents0.values()) + [coords, img]
+    if not (img.is_cuda and masks.is_cuda and masks.dtype == torch.int64 and masks.dim() == 2 and masks.is_contiguous() and coords.dim() == 2
+            and img.dim() == 3 and 1 <= len(latents0) <= _lib.ENF_SGD_MAX_SEGMENTS and masks.shape[0] > 0
+            and all(t.dtype == torch.float32 and t.is_contiguous() and t.device == img.device for t in ts)
+            and all(v.dim() == 3 and v.shape[0] == 1 for v in latents0.values())
+            and len({v.shape[1] for v in latents0.values()}) == 1):
+        return None
+    B, N, O = img.shape
+    Ns, S1 = masks.shape
+    Z = next(iter(latents0.values())).shape[1]
+    dev = img.device
+    lat = {k: torch.empty((B, Z, v.shape[2]), device=dev, dtype=torch.float32) for k, v in latents0.items()}
+    xs = torch.empty((S1, Ns, coords.shape[1]), device=dev, dtype=torch.float32)
+    ys = torch.empty((S1, B, Ns, O), device=dev, dtype=torch.float32)
+    losses = torch.empty(S1, device=dev, dtype=torch.float32)
+    comps = (_lib.EnfFitComponent * _lib.ENF_SGD_MAX_SEGMENTS)()
+    keep = []
+    for i, (k, v) in enumerate(latents0.items()):
+        src = v.detach()
+        keep.append(src)
+        comps[i] = _lib.EnfFitComponent(src.data_ptr(), lat[k].data_ptr(), v.shape[2], 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.launch(dev, _lib.load().enf_fit_inputs, len(latents0), comps, B, Z, N, Ns, S1, coords.shape[1], O, coords.data_ptr(), img.data_ptr(),
+                masks.data_ptr(), xs.data_ptr(), ys.data_ptr(), losses.data_ptr(), st)
+    return lat, xs, ys, losses
+
+
 def _pose(lat, num_ori_dims):
     return torch.cat((lat["p_pos"], lat["p_ori"]), dim=-1) if num_ori_dims > 0 else lat["p_pos"]
 
@@ -66,16 +99,20 @@ def inner_loop(nef, nef_params, latents0, lrs, coords, img, masks, optimize_gaus
     B = img.shape[0]
     S = masks.shape[1] - 1
     n_ori = nef.cross_attn_invariant.num_z_ori_dims
-    lat = {k: v.detach().repeat_interleave(B, dim=0) for k, v in latents0.items()}           # pde_trainer.py:157-159 (a fresh tensor)
+    fused = _fit_inputs(latents0, coords, img, masks) if FUSED_FIT_INPUTS else None
+    if fused is not None:
+        # the signals' copies of the latent initialisation (pde_trainer.py:157-159), the coordinates and targets of all S+1 steps
+        # gathered once (:193-197) and the zeroed loss accumulators: ONE launch (enf_fit_inputs) instead of eight framework kernels
+        lat, xs_all, ys_all, losses = fused
+    else:
+        lat = {k: v.detach().repeat_interleave(B, dim=0) for k, v in latents0.items()}       # pde_trainer.py:157-159 (a fresh tensor)
+        masks_t = masks.t().contiguous()                                     # (a gather inherits the strides of a transposed index)
+        xs_all = coords[masks_t]                                             # (S+1, N_s, dx)
+        ys_all = img[:, masks_t].transpose(0, 1).float().contiguous()        # (S+1, B, N_s, O)
+        losses = torch.zeros(S + 1, device=img.device, dtype=torch.float32)  # one accumulator per step, zeroed in one fill
     if noise_pos:                                                                             # pde_trainer.py:162-167
         lat["p_pos"] = lat["p_pos"] + torch.randn(lat["p_pos"].shape, generator=generator,
                                                   device="cpu").to(lat["p_pos"].device) * noise_pos
-
-    # coordinates and targets of all S+1 steps gathered once                 (pde_trainer.py:193-197)
-    masks_t = masks.t().contiguous()                                     # (a gather inherits the strides of a transposed index)
-    xs_all = coords[masks_t]                                             # (S+1, N_s, dx)
-    ys_all = img[:, masks_t].transpose(0, 1).float().contiguous()        # (S+1, B, N_s, O)
-    losses = torch.zeros(S + 1, device=img.device, dtype=torch.float32)  # one accumulator per step, zeroed in one fill
     n_pos = lat["p_pos"].shape[-1]
     for s in range(S):                                                  # pde_trainer.py:191
         xs = xs_all[s][None].expand(B, -1, -1)                          # stride-0 batch

@@ -295,6 +295,20 @@ typedef struct EnfSgdSegment {
 } EnfSgdSegment;
 int enf_meta_sgd_update(int nseg, const EnfSgdSegment* segs, float scale, void* stream);
 
+/* What the inner loop prepares before its first step, in ONE launch (pde_trainer.py:157-159, 193-197; six framework kernels otherwise):
+ *   - every latent component of the shared initialisation, (1, Z, width), repeated for the B signals -> (B, Z, width);
+ *   - the coordinates and the targets of all S1 = S + 1 sampled point sets gathered once:
+ *       xs[s, i, :] = coords[masks[i, s], :]     (S1, Ns, dx)       ys[s, b, i, :] = img[b, masks[i, s], :]     (S1, B, Ns, O)
+ *     with masks (Ns, S1) int64 indices into the N grid points, coords (N, dx), img (B, N, O), all fp32 and contiguous;
+ *   - the S1 loss accumulators zeroed. */
+typedef struct EnfFitComponent {
+  const float* src; /* (1, Z, width) */
+  float* dst;       /* (B, Z, width) */
+  int32_t width, reserved;
+} EnfFitComponent;
+int enf_fit_inputs(int ncomp, const EnfFitComponent* comps, int32_t B, int32_t Z, int32_t N, int32_t Ns, int32_t S1, int32_t dx, int32_t O,
+                   const float* coords, const float* img, const int64_t* masks, float* xs, float* ys, float* losses, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Latent ODE (experiments/fitting/ode_models/ponita_ode_g.py): the separable group convolution of a ConvBlock,
  * SepGconv.__call__ (:63-83), over the fully connected latent set of every signal:

@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 k = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
 # a step ends with the decode-shape forward pair kernel (z-fold instantiation <.., true, true>) and its tail
-dec = [i for i, (n, s, e) in enumerate(k) if re.search(r"enf_pair_fwd_kernel<\d+, \d+, (true|false), true(, (true|false))?>", n)]
+dec = [i for i, (n, s, e) in enumerate(k) if re.search(r"enf_pair_fwd_kernel<\d+, \d+, (true|false), true(, [^>]*)?>", n)]
 a, b = dec[3], dec[4]
 seg = k[a + 2:b + 2]
 t0, busy, prev = seg[0][1], 0, None

@@ -49,3 +49,29 @@ def test_update_rejects_bad_segments(cuda):
     assert lib.enf_meta_sgd_update(1, seg, 1.0, None) == -1       # rows of g overlap
     seg[0].g_stride, seg[0].x = 6, None
     assert lib.enf_meta_sgd_update(1, seg, 1.0, None) == -1
+
+
+@pytest.mark.parametrize("B,Z,N,Ns,S,dx,O,ori", [(16, 64, 4096, 512, 3, 2, 1, False), (3, 7, 100, 37, 2, 3, 3, True), (1, 1, 5, 5, 0, 2, 1, False)])
+def test_fit_inputs_in_one_launch_equal_the_framework_ops(cuda, B, Z, N, Ns, S, dx, O, ori):
+    """enf_fit_inputs (inner_loop's setup: the signals' copies of the latent initialisation, the gathered coordinates / targets of all
+    S + 1 point sets, zeroed loss accumulators; pde_trainer.py:157-159, 193-197) against the torch operations it replaces: bit for bit."""
+    from enf_pde_amd.fitting.inner_loop import _fit_inputs
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    lat0 = {"p_pos": torch.randn(1, Z, dx, generator=g), "a": torch.randn(1, Z, 9, generator=g), "gaussian_window": torch.rand(1, Z, 1, generator=g)}
+    if ori:
+        lat0["p_ori"] = torch.randn(1, Z, 1, generator=g)
+    lat0 = {k: v.to(cuda) for k, v in lat0.items()}
+    coords = torch.randn(N, dx, generator=g).to(cuda)
+    img = torch.randn(B, N, O, generator=g).to(cuda)
+    masks = torch.stack([torch.randperm(N, generator=g)[:Ns] for _ in range(S + 1)], dim=1).to(cuda)
+    got = _fit_inputs(lat0, coords, img, masks)
+    assert got is not None
+    lat, xs, ys, losses = got
+    mt = masks.t().contiguous()
+    for k, v in lat0.items():
+        assert torch.equal(lat[k], v.repeat_interleave(B, dim=0))
+    assert torch.equal(xs, coords[mt]) and torch.equal(ys, img[:, mt].transpose(0, 1).contiguous())
+    assert losses.shape == (S + 1,) and float(losses.abs().sum()) == 0.0
+    # arguments the kernel does not take fall back to the framework path
+    assert _fit_inputs(lat0, coords.double(), img, masks) is None and _fit_inputs(lat0, coords, img, masks.int()) is None
+
